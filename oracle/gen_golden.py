@@ -1,0 +1,283 @@
+#!/usr/bin/env python3
+"""Record golden vectors from the reference itself (build container only).
+
+TEST INFRASTRUCTURE ONLY.  Imports /root/reference through oracle/ref_harness.py, drives its
+classes with scripted / seeded inputs and writes small .npz fixtures into tests/golden/.
+Only data (inputs + the reference's outputs) is written; no reference source text is stored.
+
+  python oracle/gen_golden.py [traces] [views] [her] [ppo] [predictor]     (default: all)
+
+The random draws of Twoarmy (np.random.choice calls in twoarmy_v{4,6}.py) are replaced by the
+engine's counter-based Philox words (oracle/philox.py) through ref_harness.patched_choice, so
+reference, oracle and HIP engine all consume identical draws per (env, step, slot).
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import philox  # noqa: E402
+import ref_harness as rh  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(HERE), "tests", "golden")
+SEED = 9981  # reference default, soa/train_ppo.py:25
+
+ERR_CODE = {AttributeError: 1, AssertionError: 2, TypeError: 3}
+OP_RESET = -1
+
+
+# ----------------------------------------------------------------------------- draws
+class PhiloxSlots:
+    """draw_fn for ref_harness.SlotRecorder: identifies the slot from (lo, n) + call order in the step."""
+
+    def __init__(self, seed, env_id):
+        self.seed, self.env_id = seed, env_id
+        self.t = 0            # index of the current step() call
+        self.calls = []       # (lo, n) seen in the current step
+        self.log = []         # (t, slot, lo, n, value)
+
+    def begin_step(self, t):
+        self.t, self.calls = t, []
+
+    def slot_of(self, lo, n):
+        if (lo, n) == (0, 10):
+            return philox.S_GATE
+        if (lo, n) == (9, 4):
+            return philox.S_WALL1
+        if (lo, n) == (6, 4):
+            return philox.S_WALL2 if (self.calls and self.calls[-1] == (9, 4)) else philox.S_SPAWN
+        if (lo, n) == (4, 1):
+            return 6          # choice(range(4,5)): single outcome
+        if (lo, n) == (0, 2):
+            return philox.S_COIN_B if (0, 2) in self.calls else philox.S_COIN_A
+        raise AssertionError("unexpected draw range (%d,%d)" % (lo, n))
+
+    def __call__(self, lo, n):
+        slot = self.slot_of(lo, n)
+        self.calls.append((lo, n))
+        w = int(philox.draw_word(self.seed, self.env_id, self.t, slot))
+        v = lo + w % n
+        self.log.append((self.t, slot, lo, n, v))
+        return v
+
+
+def snapshot(env):
+    def pos(objs):
+        return [(-1, -1) if o.cur_pos is None else tuple(int(v) for v in o.cur_pos) for o in objs]
+    return dict(
+        agent=np.array(env.agent_pos, np.int32),
+        scal=np.array([env.step_count, env.step_move, env.pone, env.patrol, env.up1, env.right2,
+                       env.Update_longitudinal, env.Update_horizontal, env.risk_count,
+                       env.first_to_room2, env.agent_dir], np.int32),
+        balls=np.array(pos(env.obstacles), np.int32),
+        o1=np.array(pos(env.obstacles1), np.int32),
+        o2=np.array(pos(env.obstacles2), np.int32),
+        grid=env.grid.encode().copy(),
+    )
+
+
+SCAL_NAMES = ["step_count", "step_move", "pone", "patrol", "up1", "right2", "Update_longitudinal",
+              "Update_horizontal", "risk_count", "first_to_room2", "agent_dir"]
+
+
+def run_trace(variant, ops, env_id, seed=SEED, natural_rng_seed=None):
+    """Replay `ops` (env actions >= 0, OP_RESET) on a fresh reference env; returns dict of arrays."""
+    env_buffer, _ = rh.soa_modules()
+    et = env_buffer.Env_transact()
+    slots = PhiloxSlots(seed, env_id)
+    nat_log = []
+    if natural_rng_seed is None:
+        rec = rh.SlotRecorder(slots)
+    else:
+        # K8: the reference's own MT19937 stream, recorded so it can be replayed as explicit draws
+        np.random.seed(natural_rng_seed)
+        real_choice = np.random.choice
+
+        def nat(lo, n):
+            v = int(real_choice(range(lo, lo + n), 1).item()) if n > 1 else lo
+            slot = slots.slot_of(lo, n)
+            slots.calls.append((lo, n))
+            nat_log.append((slots.t, slot, lo, n, v))
+            return v
+        rec = rh.SlotRecorder(nat)
+    with rh.patched_choice(rec):
+        env = rh.make_env(variant)
+        rows = []
+        t = 0
+        for op in ops:
+            row = dict(op=op, err=0, obs=np.zeros((17, 17, 3), np.uint8), reward=np.nan, term=0, trunc=0)
+            if op == OP_RESET:
+                row["obs"] = env.reset()["image"].copy()
+            else:
+                slots.begin_step(t)
+                t += 1
+                try:
+                    obs, r, te, tr, _ = env.step(op)
+                    row.update(obs=obs["image"].copy(), reward=float(r), term=int(te), trunc=int(tr))
+                except tuple(ERR_CODE) as ex:
+                    row["err"] = ERR_CODE[type(ex)]
+            row.update(snapshot(env))
+            row["matrix"] = et.matrix_env(env).copy()
+            a, g = et.data_env(env)
+            row["pos"] = np.concatenate([a, g])
+            rows.append(row)
+    out = {k: np.stack([np.asarray(r[k]) for r in rows]) for k in rows[0]}
+    log = nat_log if natural_rng_seed is not None else slots.log
+    out["draw_log"] = np.array(log, np.int64).reshape(-1, 5)
+    out["variant"] = np.int32(4 if variant == "v4" else 6)
+    out["env_id"] = np.int32(env_id)
+    out["natural"] = np.int32(natural_rng_seed is not None)
+    return out
+
+
+def random_ops(rs, n, p=(0.2, 0.2, 0.2, 0.2, 0.2), reset_after_done=True):
+    """Policy indices -> env actions (4 -> 6).  Resets are inserted lazily by the caller."""
+    idx = rs.choice(5, size=n, p=p)
+    return [6 if a == 4 else int(a) for a in idx]
+
+
+def gen_traces():
+    traces = []
+    R = OP_RESET
+    # --- scripted v6 known-answer traces
+    v6_scripts = {
+        "K1_wall_drop": [1, 6, 6],
+        "K2_blocked_room2": [1, 1, 1] + [2] * 12,
+        "K3_risk_trunc": [1] * 4 + [2] * 6 + [6] * 20,
+        "K4_goal": [1] * 7 + [2] * 7 + [6, 6] + [2] * 6 + [1] * 4 + [6, 2, 1, R, 1, 2],
+        "K5_ball_onto_agent": [1] * 7 + [2] * 7 + [6] * 5 + [6, 6, 2, 2, R, 2],
+        "K6_timeout": [0] * 50 + [0, 1, R, 1],
+        "K7_illegal": [4, 5, 7, 99, 1, 4, 2, 5],
+        "K9_midreset": [1, 1, 2, 2, R, 2, 2, 1, 1, R, 1] + [2] * 10,
+        "K10_nodone_reset": [1] * 7 + [2] * 7 + [6] * 5 + [6] * 40 + [1] * 30,  # keep stepping past done, never reset
+        "K11_drift": [1] * 4 + [2] * 6 + [6] * 20 + [6] * 200,                 # risk truncations without reset: ball drift
+    }
+    eid = 0
+    for name, ops in v6_scripts.items():
+        tr = run_trace("v6", ops, eid)
+        tr["name"] = np.array(name)
+        traces.append(tr)
+        eid += 1
+    # --- random v6 traces with the training loop's reset-after-done
+    for k in range(6):
+        rs = np.random.RandomState(1000 + k)
+        p = (0.2,) * 5 if k < 3 else (0.1, 0.3, 0.35, 0.1, 0.15)
+        traces.append(_random_trace("v6", rs, 160, p, eid, "rand_v6_%d" % k))
+        eid += 1
+    # --- v4: scripted path into room 2 (K8 path) then wander, Philox draws
+    path = [1] * 7 + [2] * 7
+    v4_scripts = {
+        "v4_room2_wait": path + [2] + [6] * 40,
+        "v4_room2_goal": path + [2] * 7 + [1] * 4 + [6, 6],
+        "v4_room2_patrol_left": path + [2, 2, 2] + [0] * 6 + [2, 2, 1, 1] + [6] * 10,
+        "v4_room2_patrol_right": path + [2, 2] + [1] * 2 + [2] * 3 + [6] * 12,
+        "v4_illegal_midreset": path + [2, 2, 4, 2, R, 2, 2],   # reset with patrol=True: TypeError on next step
+        "v4_nodone": path + [2] * 3 + [6] * 120,
+    }
+    for name, ops in v4_scripts.items():
+        for rep in range(2):   # two env ids -> different draws
+            tr = run_trace("v4", ops, eid)
+            tr["name"] = np.array("%s_%d" % (name, rep))
+            traces.append(tr)
+            eid += 1
+    for k in range(10):
+        rs = np.random.RandomState(2000 + k)
+        p = (0.1, 0.3, 0.35, 0.1, 0.15) if k % 2 == 0 else (0.15, 0.25, 0.3, 0.1, 0.2)
+        traces.append(_random_trace("v4", rs, 200, p, eid, "rand_v4_%d" % k))
+        eid += 1
+    # --- K8: the reference's natural MT19937 stream, np.random.seed(9981)
+    tr = run_trace("v4", path + [2, 2, 2] + [6] * 30, eid, natural_rng_seed=9981)
+    tr["name"] = np.array("K8_natural_seed9981")
+    traces.append(tr)
+    eid += 1
+    tr = run_trace("v6", [1] * 7 + [2] * 7 + [6] * 5 + [R] + [1] * 4 + [2] * 6 + [6] * 20, eid, natural_rng_seed=7)
+    tr["name"] = np.array("v6_natural_seed7")
+    traces.append(tr)
+    eid += 1
+
+    flat = {}
+    for i, tr in enumerate(traces):
+        for k, v in tr.items():
+            if k in ("grid", "obs"):
+                v = v.astype(np.uint8)
+            flat["t%02d_%s" % (i, k)] = v
+    flat["n_traces"] = np.int32(len(traces))
+    flat["scal_names"] = np.array(SCAL_NAMES)
+    flat["seed"] = np.int64(SEED)
+    path_out = os.path.join(GOLD, "twoarmy_traces.npz")
+    np.savez_compressed(path_out, **flat)
+    nsteps = sum(len(tr["op"]) for tr in traces)
+    print("traces: %d traces, %d ops -> %s (%.1f KB)" % (len(traces), nsteps, path_out,
+                                                         os.path.getsize(path_out) / 1024))
+
+
+def _random_trace(variant, rs, n, p, eid, name):
+    """Random policy with reset after every done step (soa/train_ppo.py:104,126,154)."""
+    # Two-pass: first discover where dones happen (needs the env), so generate ops online.
+    ops = []
+    env_actions = random_ops(rs, n, p)
+    # online replay to insert resets
+    slots = PhiloxSlots(SEED, eid)
+    rec = rh.SlotRecorder(slots)
+    with rh.patched_choice(rec):
+        env = rh.make_env(variant)
+        t = 0
+        for a in env_actions:
+            slots.begin_step(t)
+            t += 1
+            _, _, te, tr, _ = env.step(a)
+            ops.append(a)
+            if te or tr:
+                env.reset()
+                ops.append(OP_RESET)
+    tr = run_trace(variant, ops, eid)
+    tr["name"] = np.array(name)
+    return tr
+
+
+# ----------------------------------------------------------------------------- views
+def gen_views():
+    """gen_obs_grid(V).encode() for dirs 0-3 x V in {3,5,7,17} on rich v4 states (minigrid.py:1443-1478)."""
+    slots = PhiloxSlots(SEED, 900)
+    rec = rh.SlotRecorder(slots)
+    grids, agents, dirs, views, images = [], [], [], [], {}
+    with rh.patched_choice(rec):
+        env = rh.make_env("v4")
+        ops = [1] * 7 + [2] * 7 + [2, 2, 6, 6]
+        for t, a in enumerate(ops):
+            slots.begin_step(t)
+            env.step(a)
+        positions = [(1, 1), (15, 15), (1, 15), (15, 1), (8, 8), (3, 15), (10, 6), (13, 3), (6, 10), (14, 2), (5, 12)]
+        case = 0
+        for (x, y) in positions:
+            for d in range(4):
+                env.agent_pos = (x, y)
+                env.agent_dir = d
+                for V in (3, 5, 7, 17):
+                    g, _ = env.gen_obs_grid(V)
+                    images["img_%03d_V%d" % (case, V)] = g.encode().astype(np.uint8)
+                grids.append(env.grid.encode().astype(np.uint8))
+                agents.append((x, y))
+                dirs.append(d)
+                case += 1
+    out = dict(grid=np.stack(grids), agent=np.array(agents, np.int32), dir=np.array(dirs, np.int32),
+               view_sizes=np.array([3, 5, 7, 17], np.int32), **images)
+    path_out = os.path.join(GOLD, "views.npz")
+    np.savez_compressed(path_out, **out)
+    print("views: %d cases x 4 sizes -> %s (%.1f KB)" % (len(grids), path_out, os.path.getsize(path_out) / 1024))
+
+
+STAGES = {"traces": gen_traces, "views": gen_views}
+
+
+def main(argv):
+    os.makedirs(GOLD, exist_ok=True)
+    want = argv or list(STAGES)
+    for name in want:
+        STAGES[name]()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
