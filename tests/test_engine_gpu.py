@@ -1,0 +1,200 @@
+"""HIP engine (through the C ABI) vs golden vectors from the reference and vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+import twoarmy_oracle as orc
+from golden_util import SCAL, explicit_draws, load_traces
+
+pytestmark = pytest.mark.gpu
+
+TRACES, SEED = load_traces()
+F = None
+
+
+def _engine(*a, **k):
+    from twoarmy_amd.engine import TwoarmyEngine
+    return TwoarmyEngine(*a, **k)
+
+
+def _fields():
+    from twoarmy_amd._lib import FIELDS
+    return FIELDS
+
+
+def _grid_encode(ty, co):
+    t = ty.reshape(17, 17)
+    c = co.reshape(17, 17)
+    return np.stack([t.T, c.T, np.zeros_like(t.T)], axis=-1)
+
+
+@pytest.mark.parametrize("idx", range(len(TRACES)))
+def test_trace_vs_reference_golden(idx):
+    """Every recorded reference trace replayed one tw_step at a time (N=1, no auto-reset)."""
+    tr = TRACES[idx]
+    Fd = _fields()
+    eng = _engine(int(tr["variant"]), 1, 17, seed=SEED, env_id0=int(tr["env_id"]))
+    out = eng.alloc_outputs()
+    nat = explicit_draws(tr) if int(tr["natural"]) else None
+    act = torch.zeros(1, dtype=torch.int32, device="cuda")
+    t = 0
+    for k, op in enumerate(tr["op"]):
+        ctx = "%s op#%d=%d" % (tr["name"], k, op)
+        if op == -1:
+            obs = torch.empty((1, 17, 17, 3), dtype=torch.uint8, device="cuda")
+            eng.reset(obs=obs)
+            assert np.array_equal(obs.cpu().numpy()[0], tr["obs"][k]), ctx
+            ty, co, rec = eng.get_state()
+        else:
+            act[0] = int(op)
+            draws = None
+            if nat is not None:
+                w = nat.get(t, np.zeros(8, np.uint32))
+                draws = torch.from_numpy(w.view(np.int32).copy()).cuda().reshape(1, 8)
+            t += 1
+            eng.step(act, out, draws=draws)
+            ty, co, rec = eng.get_state()
+            err = int(rec[0, Fd["ERROR"]])
+            assert err == int(tr["err"][k]), ctx
+            if err == 0:
+                assert np.array_equal(out["obs"].cpu().numpy()[0], tr["obs"][k]), ctx
+                assert out["reward"].item() == np.float32(tr["reward"][k]), ctx
+                assert bool(out["terminated"].item()) == bool(tr["term"][k]), ctx
+                assert bool(out["truncated"].item()) == bool(tr["trunc"][k]), ctx
+                assert np.array_equal(out["matrix"].cpu().numpy()[0], tr["matrix"][k].astype(np.float32)), ctx
+                assert out["pos"].cpu().numpy()[0].tolist() == tr["pos"][k][:2].tolist(), ctx
+        r = rec[0]
+        assert (r[Fd["AX"]], r[Fd["AY"]]) == tuple(tr["agent"][k]), ctx
+        names = ["STEP_COUNT", "STEP_MOVE", "PONE", "PATROL", "UP1", "RIGHT2", "UPD_LONG", "UPD_HORIZ", "RISK",
+                 "FIRST_ROOM2", "DIR"]
+        for j, nm in enumerate(names):
+            assert int(r[Fd[nm]]) == int(tr["scal"][k][j]), ctx + " " + nm
+        balls = [(r[Fd["OBX"] + i], r[Fd["OBY"] + i]) for i in range(3)]
+        assert balls == list(map(tuple, tr["balls"][k])), ctx
+        if r[Fd["O1_VALID"]]:
+            assert [(r[Fd["O1X"] + i], r[Fd["O1Y"] + i]) for i in range(3)] == list(map(tuple, tr["o1"][k])), ctx
+        else:
+            assert (tr["o1"][k] == -1).all(), ctx
+        if r[Fd["O2_VALID"]]:
+            assert [(r[Fd["O2X"] + i], r[Fd["O2Y"] + i]) for i in range(4)] == list(map(tuple, tr["o2"][k])), ctx
+        else:
+            assert (tr["o2"][k] == -1).all(), ctx
+        assert np.array_equal(_grid_encode(ty[0], co[0]), tr["grid"][k]), ctx
+        assert (r[Fd["GOAL_Y"]], r[Fd["GOAL_X"]]) == tuple(tr["pos"][k][2:].astype(int)), ctx
+    eng.close()
+
+
+def test_views_vs_reference_golden(golden_dir):
+    """gen_obs_grid(V).encode() for dirs 0-3 x V in {3,5,7,17} (closed-form rotation)."""
+    z = np.load(golden_dir + "/views.npz")
+    Fd = _fields()
+    ncase = len(z["dir"])
+    eng = _engine(4, ncase, 17, seed=SEED)
+    ty, co, rec = eng.get_state()
+    for c in range(ncase):
+        g = z["grid"][c]
+        ty[c] = np.ascontiguousarray(g[:, :, 0].T).reshape(-1)
+        co[c] = np.ascontiguousarray(g[:, :, 1].T).reshape(-1)
+        rec[c, Fd["AX"]], rec[c, Fd["AY"]] = z["agent"][c]
+        rec[c, Fd["DIR"]] = z["dir"][c]
+    eng.set_state(ty, co, rec)
+    for V in z["view_sizes"]:
+        img = eng.gen_obs(int(V)).cpu().numpy()
+        for c in range(ncase):
+            assert np.array_equal(img[c], z["img_%03d_V%d" % (c, V)]), (c, int(V))
+    eng.close()
+
+
+def _compare_rollout(variant, N, T, view, env0=0, chunk=None):
+    eng = _engine(variant, N, view, seed=SEED, env_id0=env0)
+    ref = orc.rollout(variant, N, T, SEED, env0=env0, view=view)
+    out = eng.alloc_outputs(T)
+    if chunk is None:
+        eng.rollout(T, out)
+    else:                                  # same thing in several launches: state must carry over exactly
+        for t0 in range(0, T, chunk):
+            t1 = min(T, t0 + chunk)
+            sub = {k: (v[t0:t1] if v is not None else None) for k, v in out.items()}
+            eng.rollout(t1 - t0, sub)
+    torch.cuda.synchronize()
+    for k in ("obs", "matrix", "pos", "reward", "terminated", "truncated"):
+        got = out[k].cpu().numpy()
+        assert got.dtype == ref[k].dtype and got.shape == ref[k].shape, k
+        if not np.array_equal(got, ref[k]):
+            bad = np.argwhere(got != ref[k])[0]
+            raise AssertionError("%s mismatch first at %s: got %s want %s" % (k, bad, got[tuple(bad)], ref[k][tuple(bad)]))
+    eng.close()
+    return ref
+
+
+@pytest.mark.parametrize("variant", [6, 4])
+def test_rollout_4096_vs_oracle(variant):
+    """BASELINE config 2: 4096 envs, fused T-step launch, bit-exact obs/matrix/reward/done vs the CPU oracle."""
+    ref = _compare_rollout(variant, 4096, 200, 17)
+    assert ref["truncated"].sum() > 0
+
+
+@pytest.mark.parametrize("variant,view,N,T,env0", [(6, 7, 513, 130, 0), (4, 7, 257, 150, 12345), (4, 3, 65, 64, 7),
+                                                   (6, 5, 1, 120, 4095), (4, 17, 1000, 100, 1 << 20)])
+def test_rollout_shapes_vs_oracle(variant, view, N, T, env0):
+    """ragged N (not a multiple of 4/64), small views, sharded env-id offsets"""
+    _compare_rollout(variant, N, T, view, env0=env0)
+
+
+@pytest.mark.parametrize("variant", [6, 4])
+def test_rollout_chunked_equals_single(variant):
+    _compare_rollout(variant, 300, 96, 17, chunk=1)      # tw_rollout(T=1) x 96 == oracle
+    _compare_rollout(variant, 300, 100, 17, chunk=33)
+
+
+def test_step_api_equals_rollout():
+    """tw_step with explicit actions == tw_rollout with Philox actions (fill_actions gives the same stream)."""
+    N, T = 777, 60
+    a = _engine(4, N, 17, seed=SEED)
+    b = _engine(4, N, 17, seed=SEED)
+    acts = a.fill_actions(T)
+    out_a = a.alloc_outputs(T)
+    a.rollout(T, out_a)
+    out_b = b.alloc_outputs(T)
+    for t in range(T):
+        sub = {k: v[t] for k, v in out_b.items()}
+        b.step(acts[t], sub, autoreset=True, policy_idx=True)
+    torch.cuda.synchronize()
+    for k in out_a:
+        assert torch.equal(out_a[k], out_b[k]), k
+    sa, sb = a.get_state(), b.get_state()
+    for x, y in zip(sa, sb):
+        assert np.array_equal(x, y)
+
+
+def test_full_size_properties():
+    """Size-independent properties at the benchmark size (4096 envs x 512 steps, v4):
+    rewards in the 5-value set; done => step_count reset; obs window consistent with the state matrix."""
+    N, T = 4096, 512
+    eng = _engine(4, N, 17, seed=SEED)
+    out = eng.alloc_outputs(T)
+    eng.rollout(T, out)
+    torch.cuda.synchronize()
+    r = out["reward"]
+    vals = torch.tensor([-0.01, -0.1, -0.9, 0.2, 0.9], device="cuda")
+    assert bool((r.unsqueeze(-1) == vals).any(-1).all())
+    m = out["matrix"]
+    assert bool(((m == 0.9) | (m == -0.9) | (m == -0.5) | (m == 0.3)).all())
+    assert bool(((m == 0.3).sum(-1) == 1).all())                       # exactly one agent cell
+    pos = out["pos"].long()
+    agent_idx = pos[..., 0] * 17 + pos[..., 1]
+    assert bool((m.gather(-1, agent_idx.unsqueeze(-1)).squeeze(-1) == 0.3).all())
+    # agent's own view cell is always empty (1,0,0); dir == 3 -> view cell (8,16)
+    assert bool((out["obs"][:, :, 8, 16, 0] == 1).all())
+    # done iff (terminated | truncated); episodes never exceed 50 steps
+    done = (out["terminated"] | out["truncated"]).bool()
+    run = torch.zeros(N, dtype=torch.long, device="cuda")
+    mx = 0
+    for t in range(T):
+        run += 1
+        mx = max(mx, int(run.max()))
+        run[done[t]] = 0
+    assert mx <= 50
+    _, _, rec = eng.get_state()
+    assert int(rec[:, _fields()["ERROR"]].max()) == 0
+    assert int(rec[:, _fields()["T"]].min()) == T
