@@ -108,6 +108,15 @@ struct EnvS {
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// One workgroup == one wavefront: LDS operations of a wave execute in issue order, so cross-lane
+// LDS hand-offs only need the COMPILER to keep program order.  __syncthreads() would also emit
+// s_waitcnt vmcnt(0) and drain every outstanding global store (several microseconds per step under load).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ void load_env(EnvS &s, const int32_t *r) {
     s.ax = rfl(r[TW_AX]); s.ay = rfl(r[TW_AY]); s.dir = rfl(r[TW_DIR]);
     s.step_count = rfl(r[TW_STEP_COUNT]); s.step_move = rfl(r[TW_STEP_MOVE]);
@@ -232,7 +241,7 @@ __device__ __forceinline__ void emit_obs(const uint32_t *cells, uint32_t *stage,
         sb[3 * c + 1] = (uint8_t)(v >> 8);
         sb[3 * c + 2] = (uint8_t)(v >> 16);
     }
-    __syncthreads();
+    wave_sync();
     const int first = (4 - (int)off) & 3;
     const int nmid = (nb - first) >> 2;
     const int tail = (nb - first) & 3;
@@ -243,7 +252,7 @@ __device__ __forceinline__ void emit_obs(const uint32_t *cells, uint32_t *stage,
         for (int d = lane; d < nmid; d += 64) gd[d] = sd[d];
     }
     if (lane < tail) dst[first + nmid * 4 + lane] = sb[first + nmid * 4 + lane];
-    __syncthreads();
+    wave_sync();
 }
 
 // Env_transact.matrix_env (soa/env_buffer.py:300-318)
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(64) void tw_rollout_kernel(Params p) {
     if (lane < REC) recs[lane] = p.rec[(size_t)n * REC + lane];
     for (int c = lane; c < NC; c += 64)
         cells[c] = (uint32_t)p.type[(size_t)n * NC + c] | ((uint32_t)p.colour[(size_t)n * NC + c] << 8);
-    __syncthreads();
+    wave_sync();
     EnvS s;
     load_env(s, recs);
 
@@ -286,8 +295,13 @@ __global__ __launch_bounds__(64) void tw_rollout_kernel(Params p) {
     const bool autoreset = (p.flags & TW_F_AUTORESET) != 0;
     const bool policy_idx = (p.flags & TW_F_POLICY_IDX) != 0 || p.actions == nullptr;
 
+    int act_vec = 0;                                  // lane l: action of step (tt & ~63) + l
     for (int tt = 0; tt < p.T; ++tt) {
         const size_t idx = (size_t)tt * N + n;
+        if (p.actions && (tt & 63) == 0) {
+            const int ts = tt + lane;
+            act_vec = ts < p.T ? p.actions[(size_t)ts * N + n] : 0;
+        }
         const uint32_t t = s.t;
         const uint32_t *dr = p.draws ? p.draws + idx * TW_DRAW_WORDS : nullptr;
         auto take = [&](uint32_t slot) -> uint32_t {
@@ -295,7 +309,7 @@ __global__ __launch_bounds__(64) void tw_rollout_kernel(Params p) {
         };
 
         int action;
-        if (p.actions) action = rfl(p.actions[idx]);
+        if (p.actions) action = __builtin_amdgcn_readlane(act_vec, tt & 63);
         else action = (int)(draw_word(p.seed_lo, p.seed_hi, env_id, t, TW_S_ACTION) % 5u);
         if (policy_idx && action == 4) action = 6;                // Env_transact.env_action
 
@@ -365,7 +379,7 @@ __global__ __launch_bounds__(64) void tw_rollout_kernel(Params p) {
             else if (action == 3) ty += 1;
             else if (action != 6) { err = TW_ENV_ATTRIBUTE; break; }   // self.actions.forward, :1397
             if (!inb(tx, ty)) { err = TW_ENV_ASSERT; break; }
-            __syncthreads();                                      // lane-0 cell writes -> all lanes
+            wave_sync();                                      // lane-0 cell writes -> all lanes
             {
                 const uint32_t cv = (uint32_t)rfl((int)cells[ty * GS + tx]);
                 const uint32_t ct = cv & 0xffu, cs = (cv >> 16) & 0xffu;
@@ -380,7 +394,7 @@ __global__ __launch_bounds__(64) void tw_rollout_kernel(Params p) {
         if (!have_obs) {           // the reference raised: state keeps the mutations made so far
             s.err = err;
             s.last_reward = -1; s.last_term = 0; s.last_trunc = 0;
-            __syncthreads();
+            wave_sync();
             continue;
         }
 
@@ -450,11 +464,11 @@ __global__ __launch_bounds__(64) void tw_rollout_kernel(Params p) {
         s.err = err;
         if (err != TW_ENV_OK) {
             s.last_reward = -1; s.last_term = 0; s.last_trunc = 0;
-            __syncthreads();
+            wave_sync();
             continue;
         }
         s.last_reward = reward; s.last_term = terminated; s.last_trunc = truncated;
-        __syncthreads();                                          // wall / spawn cell writes -> all lanes
+        wave_sync();                                          // wall / spawn cell writes -> all lanes
 
         // ================= outputs after the full step
         if (p.matrix) emit_matrix(cells, lane, s.ax, s.ay, p.matrix + idx * NC);
@@ -467,19 +481,19 @@ __global__ __launch_bounds__(64) void tw_rollout_kernel(Params p) {
 
         // ================= auto-reset (soa/train_ppo.py:104: reset() opens every episode)
         if (autoreset && (terminated || truncated)) {
-            __syncthreads();
+            wave_sync();
             for (int c = lane; c < NC; c += 64) {
                 const int y = c / GS, x = c - y * GS;
                 cells[c] = gen_cell(x, y);
             }
             reset_scalars(s);
         }
-        __syncthreads();
+        wave_sync();
     }
 
     // write state back
     if (lane == 0) store_env(s, recs);
-    __syncthreads();
+    wave_sync();
     if (lane < REC) p.rec[(size_t)n * REC + lane] = recs[lane];
     for (int c = lane; c < NC; c += 64) {
         const uint32_t v = cells[c];
