@@ -41,20 +41,23 @@ _vp = C.c_void_p
 _SIGS = {
     "tw_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32]),
     "tw_destroy": (C.c_int, [_vp]),
-    "tw_reset": (C.c_int, [_vp, _vp, _vp, _vp]),
-    "tw_step": (C.c_int, [_vp] + [_vp] * 8 + [C.c_int, _vp]),
-    "tw_rollout": (C.c_int, [_vp, C.c_int] + [_vp] * 8 + [C.c_int, _vp]),
+    "tw_reset": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
+    # (handle, actions, draws, obs, obs_pitch, matrix, mat_pitch, pos, reward, term, trunc, flags, stream)
+    "tw_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp]),
+    "tw_rollout": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp]),
+    "tw_set_envs_per_wave": (C.c_int, [_vp, C.c_int]),
     "tw_fill_actions": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "tw_state_ptrs": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "tw_get_state_host": (C.c_int, [_vp, _vp, _vp, _vp]),
     "tw_set_state_host": (C.c_int, [_vp, _vp, _vp, _vp]),
-    "tw_gen_obs": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "tw_gen_obs": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp]),
     "tw_n_envs": (C.c_int, [_vp]),
     "tw_view_size": (C.c_int, [_vp]),
     "tw_last_hip_error": (C.c_int, []),
     "tw_version": (C.c_char_p, []),
     "tw_last_error_message": (C.c_char_p, []),
-    "tw_time_rollout": (C.c_int, [_vp, C.c_int] + [_vp] * 7 + [C.c_int, C.c_int, _vp, C.POINTER(C.c_float)]),
+    "tw_time_rollout": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp,
+                                  C.POINTER(C.c_float)]),
 }
 
 _lib = None

@@ -1,30 +1,38 @@
 // twoarmy_engine.hip -- MI355X (gfx950) MiniGrid-Twoarmy step / observation engine.
 //
-// One wavefront (= one 64-thread workgroup) owns one environment.  The env's object planes
-// (type, colour: SoA uint8[N][289] in HBM) are staged into LDS as packed 32-bit cells once per
-// launch and stay there for all T steps of a rollout; the per-env scalar record is held in
-// wave-uniform registers (env index = blockIdx.x, so hipcc keeps the step logic on the scalar
-// unit).  Per step a wave
-//   1. applies the uniform transition logic (ball/patrol moves, agent move, termination),
-//   2. gathers the V x V egocentric window from LDS (closed-form rotation, OOB -> wall),
-//      stages the uint8[V][V][3] image in LDS and streams it out as aligned dwords,
-//   3. applies the post-observation logic (wall drop, patrol spawn, shaped reward, risk counter,
-//      episode-end re-arm),
-//   4. emits the fp32 289-cell state matrix, agent (y,x), reward, terminated, truncated,
-//   5. optionally re-generates the grid in place (auto-reset).
+// Design.  The MI355X scalar unit issues one instruction per cycle per CU,
+// the four SIMDs together two wave64 VALU instructions per cycle, so wave-uniform "scalar" env
+// logic is the slowest possible formulation.  The kernel therefore splits every env step into
+//
+//   LOGIC   lane-per-env: one wavefront (= one 64-thread workgroup) owns E consecutive envs and
+//           lanes 0..E-1 run the whole transition (ball / patrol moves, agent move, wall drop,
+//           patrol spawn, shaped reward, risk counter, episode-end re-arm, Philox draws) on VGPRs;
+//   EMIT    wave-per-env: all 64 lanes cooperate on one env at a time to produce its outputs:
+//             * the uint8[V][V][3] egocentric image as 16-byte chunks packed in registers from a
+//               wall-padded 33x33 LDS copy of the grid (6 ds_read_b32 + 11 VALU per lane, one
+//               global_store_dwordx4 per lane, no bounds checks, no LDS byte staging),
+//             * the fp32 289-cell state matrix straight from an LDS-resident float image
+//               (ds_read_b128 + agent-cell patch + global_store_dwordx4),
+//           with a generic byte-staging path for unaligned/dense destinations and agent_dir != 3.
+//
+// Grid planes live in HBM as SoA uint8[N][289] type / colour planes plus one int32[48] record per
+// env; they are staged into LDS once per launch and stay there for all T steps of a rollout.
+// Done envs are found with a wavefront ballot and re-generated in place (auto-reset).
 //
 // Behavioural contract (bit-exact vs the reference, checked against oracle/ + tests/golden):
 //   gym_minigrid/envs/twoarmy_v6.py:83-325, twoarmy_v4.py:82-322  (Twoarmy step)
 //   gym_minigrid/minigrid.py:1333-1441 (MiniGridEnv.step), :1262-1293, :1443-1496, :641-660,
 //   :627-639, :749-772 (view extents, slice, rotate_left, encode)
 //   soa/env_buffer.py:300-334 (matrix_env, data_env)
-// This is a from-scratch closed-form implementation; it shares no code with oracle/.
+// From-scratch closed-form implementation; shares no code with oracle/.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+
+#include <type_traits>
 
 #include "twoarmy.h"
 
@@ -34,11 +42,25 @@ constexpr int GS = TW_GRID;
 constexpr int NC = TW_CELLS;
 constexpr int REC = TW_REC_WORDS;
 
-// packed LDS cell: type | colour << 8 | state << 16   (OBJECT_TO_IDX / COLOR_TO_IDX, minigrid.py:40-67)
+// packed cell code: type | colour << 8 | state << 16   (OBJECT_TO_IDX / COLOR_TO_IDX, minigrid.py:40-67)
 constexpr uint32_t C_EMPTY = 1u;
 constexpr uint32_t C_WALL = 2u | (5u << 8);
 constexpr uint32_t C_BALL = 6u | (4u << 8);
 constexpr uint32_t C_GOAL = 8u | (1u << 8);
+
+// state-matrix values (soa/env_buffer.py:305-316) as fp32 bit patterns
+constexpr uint32_t M_FREE = 0x3f666666u;   //  0.9f
+constexpr uint32_t M_WALL = 0xbf666666u;   // -0.9f
+constexpr uint32_t M_BALL = 0xbf000000u;   // -0.5f
+constexpr uint32_t M_AGENT = 0x3e99999au;  //  0.3f
+
+// per-env LDS image: wall-padded grid codes gp[33][33] (x in -8..24, y in -16..16) + float matrix
+constexpr int GPW = 33, GPH = 33, GPX0 = 8, GPY0 = 16;
+constexpr int GP_WORDS = GPW * GPH;        // 1089
+constexpr int MAT_OFF = 1092;              // 16-byte aligned
+constexpr int MAT_WORDS = 292;             // 289 + 3 pad (zeros)
+constexpr int ENV_WORDS = MAT_OFF + MAT_WORDS;   // 1384
+constexpr int STAGE_WORDS = 220;
 
 enum { R_STEP = 0, R_RISK = 1, R_HIT = 2, R_ROOM2 = 3, R_GOAL = 4 };
 
@@ -60,10 +82,12 @@ struct Params {
     float *reward;
     uint8_t *term;
     uint8_t *trunc;
+    int obs_pitch;            // bytes between consecutive envs' images
+    int mat_pitch;            // floats between consecutive envs' matrices
     int flags;
 };
 
-// ---------------------------------------------------------------- Philox4x32-10 (uniform -> SALU)
+// ---------------------------------------------------------------- Philox4x32-10
 __device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t &c0, uint32_t &c1,
                                               uint32_t &c2, uint32_t &c3) {
 #pragma unroll
@@ -76,12 +100,11 @@ __device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t
     }
 }
 
-__device__ __forceinline__ uint32_t draw_word(uint32_t k0, uint32_t k1, uint32_t env_id, uint32_t t,
-                                              uint32_t slot) {
-    uint32_t c0 = env_id, c1 = t, c2 = slot >> 2, c3 = 0x54574F41u;
-    philox4x32_10(k0, k1, c0, c1, c2, c3);
-    const uint32_t w = slot & 3u;
-    return w == 0 ? c0 : (w == 1 ? c1 : (w == 2 ? c2 : c3));
+// all four words of one draw block: counter = (env_id, t, block, 'TWOA')
+__device__ __forceinline__ void draw_block(uint32_t k0, uint32_t k1, uint32_t env_id, uint32_t t, uint32_t block,
+                                           uint32_t (&w)[4]) {
+    w[0] = env_id; w[1] = t; w[2] = block; w[3] = 0x54574F41u;
+    philox4x32_10(k0, k1, w[0], w[1], w[2], w[3]);
 }
 
 // ---------------------------------------------------------------- grid generation
@@ -97,44 +120,39 @@ __device__ __forceinline__ uint32_t gen_cell(int x, int y) {
     return C_EMPTY;
 }
 
-// wave-uniform env scalars (names follow the reference attributes)
+__device__ __forceinline__ uint32_t mat_of_code(uint32_t code) {   // env_buffer.py:306-314
+    const uint32_t t = code & 0xffu;
+    return t == 2u ? M_WALL : (t == 6u ? M_BALL : M_FREE);
+}
+
+// per-lane env state (names follow the reference attributes)
 struct EnvS {
-    int ax, ay, dir, step_count, step_move, pone, patrol, up1, right2, upd_long, upd_horiz, risk,
+    int ax, ay, dir, step_count, step_move, m6, m4, pone, patrol, up1, right2, upd_long, upd_horiz, risk,
         first_room2;
     int obx[3], oby[3], o1x[3], o1y[3], o1v, o2x[4], o2y[4], o2v, gx, gy;
     uint32_t t;
     int err, max_steps, episodes, last_reward, last_term, last_trunc;
 };
 
-__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
-
-// One workgroup == one wavefront: LDS operations of a wave execute in issue order, so cross-lane
-// LDS hand-offs only need the COMPILER to keep program order.  __syncthreads() would also emit
-// s_waitcnt vmcnt(0) and drain every outstanding global store (several microseconds per step under load).
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 __device__ __forceinline__ void load_env(EnvS &s, const int32_t *r) {
-    s.ax = rfl(r[TW_AX]); s.ay = rfl(r[TW_AY]); s.dir = rfl(r[TW_DIR]);
-    s.step_count = rfl(r[TW_STEP_COUNT]); s.step_move = rfl(r[TW_STEP_MOVE]);
-    s.pone = rfl(r[TW_PONE]); s.patrol = rfl(r[TW_PATROL]); s.up1 = rfl(r[TW_UP1]);
-    s.right2 = rfl(r[TW_RIGHT2]); s.upd_long = rfl(r[TW_UPD_LONG]); s.upd_horiz = rfl(r[TW_UPD_HORIZ]);
-    s.risk = rfl(r[TW_RISK]); s.first_room2 = rfl(r[TW_FIRST_ROOM2]);
+    s.ax = r[TW_AX]; s.ay = r[TW_AY]; s.dir = r[TW_DIR];
+    s.step_count = r[TW_STEP_COUNT]; s.step_move = r[TW_STEP_MOVE];
+    s.m6 = (int)((uint32_t)s.step_move % 6u); s.m4 = s.step_move & 3;
+    s.pone = r[TW_PONE]; s.patrol = r[TW_PATROL]; s.up1 = r[TW_UP1];
+    s.right2 = r[TW_RIGHT2]; s.upd_long = r[TW_UPD_LONG]; s.upd_horiz = r[TW_UPD_HORIZ];
+    s.risk = r[TW_RISK]; s.first_room2 = r[TW_FIRST_ROOM2];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        s.obx[k] = rfl(r[TW_OBX + k]); s.oby[k] = rfl(r[TW_OBY + k]);
-        s.o1x[k] = rfl(r[TW_O1X + k]); s.o1y[k] = rfl(r[TW_O1Y + k]);
+        s.obx[k] = r[TW_OBX + k]; s.oby[k] = r[TW_OBY + k];
+        s.o1x[k] = r[TW_O1X + k]; s.o1y[k] = r[TW_O1Y + k];
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { s.o2x[k] = rfl(r[TW_O2X + k]); s.o2y[k] = rfl(r[TW_O2Y + k]); }
-    s.o1v = rfl(r[TW_O1_VALID]); s.o2v = rfl(r[TW_O2_VALID]);
-    s.gx = rfl(r[TW_GOAL_X]); s.gy = rfl(r[TW_GOAL_Y]);
-    s.t = (uint32_t)rfl(r[TW_T]); s.err = rfl(r[TW_ERROR]); s.max_steps = rfl(r[TW_MAX_STEPS]);
-    s.episodes = rfl(r[TW_EPISODES]); s.last_reward = rfl(r[TW_LAST_REWARD]);
-    s.last_term = rfl(r[TW_LAST_TERM]); s.last_trunc = rfl(r[TW_LAST_TRUNC]);
+    for (int k = 0; k < 4; ++k) { s.o2x[k] = r[TW_O2X + k]; s.o2y[k] = r[TW_O2Y + k]; }
+    s.o1v = r[TW_O1_VALID]; s.o2v = r[TW_O2_VALID];
+    s.gx = r[TW_GOAL_X]; s.gy = r[TW_GOAL_Y];
+    s.t = (uint32_t)r[TW_T]; s.err = r[TW_ERROR]; s.max_steps = r[TW_MAX_STEPS];
+    s.episodes = r[TW_EPISODES]; s.last_reward = r[TW_LAST_REWARD];
+    s.last_term = r[TW_LAST_TERM]; s.last_trunc = r[TW_LAST_TRUNC];
 }
 
 __device__ __forceinline__ void store_env(const EnvS &s, int32_t *r) {
@@ -167,31 +185,46 @@ __device__ __forceinline__ void reset_scalars(EnvS &s) {
 }
 
 __device__ __forceinline__ bool inb(int x, int y) { return (unsigned)x < (unsigned)GS && (unsigned)y < (unsigned)GS; }
+__device__ __forceinline__ int gpi(int x, int y) { return (y + GPY0) * GPW + x + GPX0; }
 
-// Grid.set by one lane (minigrid.py:599-602); false where the reference's bounds assert fires.
-__device__ __forceinline__ bool set_cell(uint32_t *cells, int lane, int x, int y, uint32_t v) {
-    if (!inb(x, y)) return false;
-    if (lane == 0) cells[y * GS + x] = v;
-    return true;
+// One workgroup == one wavefront: LDS operations of a wave execute in issue order, so cross-lane
+// LDS hand-offs only need the COMPILER to keep program order.  __syncthreads() would also emit
+// s_waitcnt vmcnt(0) and drain every outstanding global store (microseconds per step under load).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Patrol group move: clear every cell, then put each ball at +d inside try/except
-// (twoarmy_v4.py:119-176).  n <= 4.
+// Grid.set on the env's LDS image: code plane + float matrix image (no bounds check here).
+__device__ __forceinline__ void put(uint32_t *env, int x, int y, uint32_t code, uint32_t mval) {
+    env[gpi(x, y)] = code;
+    env[MAT_OFF + y * GS + x] = mval;
+}
+
+// Patrol group move: clear every cell, then put each ball at +d inside try/except (twoarmy_v4.py:119-176).
 template <int NB>
-__device__ __forceinline__ bool move_group(uint32_t *cells, int lane, int (&xs)[NB], int (&ys)[NB], int valid,
-                                           int dx, int dy, int &err) {
-    if (!valid) { err = TW_ENV_TYPE; return false; }
+__device__ __forceinline__ bool move_group(uint32_t *env, int (&xs)[NB], int (&ys)[NB], int valid, int dx, int dy,
+                                           int &err) {
+    if (!valid) { err = TW_ENV_TYPE; return false; }      // cur_pos is None
+    bool ok = true;
 #pragma unroll
     for (int k = 0; k < NB; ++k)
-        if (!set_cell(cells, lane, xs[k], ys[k], C_EMPTY)) { err = TW_ENV_ASSERT; return false; }
+        if (ok) { if (inb(xs[k], ys[k])) put(env, xs[k], ys[k], C_EMPTY, M_FREE); else ok = false; }
+    if (!ok) { err = TW_ENV_ASSERT; return false; }
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
         const int nx = xs[k] + dx, ny = ys[k] + dy;
-        if (set_cell(cells, lane, nx, ny, C_BALL)) { xs[k] = nx; ys[k] = ny; }
+        if (inb(nx, ny)) { put(env, nx, ny, C_BALL, M_BALL); xs[k] = nx; ys[k] = ny; }
     }
     return true;
 }
 
+__device__ __forceinline__ float reward_value(int code) {
+    return code == R_STEP ? -0.01f : code == R_RISK ? -0.1f : code == R_HIT ? -0.9f : code == R_ROOM2 ? 0.2f : 0.9f;
+}
+
+// ---------------------------------------------------------------- observation: generic path
 // gen_obs_grid + encode (minigrid.py:1443-1496) in closed form.
 //   view cell (i, j) (i = x index of the rotated view, j = y index; output byte (i*V + j)*3 + ch)
 //   maps to slice coords   dir 0: (V-1-j, i)   1: (V-1-i, V-1-j)   2: (j, V-1-i)   3: (i, j)
@@ -199,22 +232,10 @@ __device__ __forceinline__ bool move_group(uint32_t *cells, int lane, int (&xs)[
 // Out-of-grid cells read as Wall (2,5,0) (minigrid.py:655-656); the agent's own cell (V/2, V-1) is
 // forced empty (minigrid.py:1472-1476, carrying is always None in Twoarmy).
 // The image is staged in LDS at the same 4-byte phase as its global destination and copied out as
-// aligned dwords (+ <= 3 head / tail bytes).
-struct ViewIdx { int i[5], j[5]; };   // per-lane view coords of cells lane + 64k (hoisted out of the step loop)
-
-__device__ __forceinline__ ViewIdx make_view_idx(int lane, int V) {
-    ViewIdx w;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const int c = lane + 64 * k;
-        w.i[k] = c / V;
-        w.j[k] = c - w.i[k] * V;
-    }
-    return w;
-}
-
-__device__ __forceinline__ void emit_obs(const uint32_t *cells, uint32_t *stage, int lane, int V, int ax, int ay,
-                                         int dir, uint8_t *dst, const ViewIdx &w) {
+// aligned dwords (+ <= 3 head / tail bytes).  Works for any destination alignment and any dir.
+template <typename Fetch>
+__device__ __forceinline__ void emit_obs_generic(Fetch fetch, uint32_t *stage, int lane, int V, int ax, int ay,
+                                                 int dir, uint8_t *dst) {
     const int VV = V * V, h = V >> 1, nb = VV * 3;
     int topx, topy;
     if (dir == 0) { topx = ax; topy = ay - h; }
@@ -224,18 +245,15 @@ __device__ __forceinline__ void emit_obs(const uint32_t *cells, uint32_t *stage,
     const int c_agent = h * V + V - 1;
     const uint32_t off = (uint32_t)(uintptr_t)dst & 3u;
     uint8_t *sb = reinterpret_cast<uint8_t *>(stage) + off;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const int c = lane + 64 * k;
-        if (c >= VV) break;
-        const int i = w.i[k], j = w.j[k];
+    for (int c = lane; c < VV; c += 64) {
+        const int i = c / V, j = c - i * V;
         int sx, sy;
         if (dir == 0) { sx = V - 1 - j; sy = i; }
         else if (dir == 1) { sx = V - 1 - i; sy = V - 1 - j; }
         else if (dir == 2) { sx = j; sy = V - 1 - i; }
         else { sx = i; sy = j; }
         const int x = topx + sx, y = topy + sy;
-        uint32_t v = inb(x, y) ? cells[y * GS + x] : C_WALL;
+        uint32_t v = inb(x, y) ? fetch(x, y) : C_WALL;
         if (c == c_agent) v = C_EMPTY;
         sb[3 * c + 0] = (uint8_t)v;
         sb[3 * c + 1] = (uint8_t)(v >> 8);
@@ -255,258 +273,534 @@ __device__ __forceinline__ void emit_obs(const uint32_t *cells, uint32_t *stage,
     wave_sync();
 }
 
-// Env_transact.matrix_env (soa/env_buffer.py:300-318)
-__device__ __forceinline__ void emit_matrix(const uint32_t *cells, int lane, int ax, int ay, float *dst) {
+// ---------------------------------------------------------------- observation: fast path
+// agent_dir == 3 (always, in Twoarmy) and a 16-byte aligned destination.  Lane l owns output
+// bytes [16l, 16l+16): they cover view cells c0 .. c0+5 with c0 = floor(16l/3); view cell
+// c = i*V + j lies at padded-grid offset (j-(V-1))*33 + (i-h) from the agent's own cell, so the
+// six gathers are one ds_read_b32 each at (agent cell address + per-lane constant).  The 24-bit
+// codes are packed into a 144-bit stream and funnel-shifted by the lane's byte phase (16l mod 3).
+// and/or masks patch the agent's own view cell to (1,0,0) and zero the bytes past V*V*3.
+struct ObsFast {
+    int rel4[6];
+    uint32_t shift;
+    uint32_t andm[4], orm[4];
+    int active;
+};
+
+__device__ __forceinline__ ObsFast make_obs_fast(int lane, int V) {
+    ObsFast f;
+    const int VV = V * V, h = V >> 1, nb = VV * 3;
+    const int nchunks = (nb + 15) >> 4;
+    f.active = lane < nchunks;
+    const int s0 = 16 * lane;
+    const int c0 = s0 / 3;
+    f.shift = 8u * (uint32_t)(s0 - 3 * c0);
+    const int c_agent = h * V + V - 1;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        int c = c0 + k;
+        if (c >= VV) c = 0;
+        const int i = c / V, j = c - i * V;
+        f.rel4[k] = f.active ? 4 * ((j - (V - 1)) * GPW + (i - h)) : 0;   // idle lanes read the agent cell
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        uint32_t am = 0, om = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int sbyte = s0 + 4 * w + b;
+            const int c = sbyte / 3, ch = sbyte - 3 * c;
+            if (sbyte >= nb) continue;                              // zero the pad bytes
+            if (c == c_agent) { if (ch == 0) om |= 1u << (8 * b); } // (1,0,0)
+            else am |= 0xffu << (8 * b);
+        }
+        f.andm[w] = am; f.orm[w] = om;
+    }
+    return f;
+}
+
+__device__ __forceinline__ void emit_obs_fast(const uint32_t *env, int ax, int ay, const ObsFast &f, int lane,
+                                              uint8_t *dst) {
+    if (!f.active) return;
+    const char *base = reinterpret_cast<const char *>(env + gpi(ax, ay));
+    uint32_t c[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) c[k] = *reinterpret_cast<const uint32_t *>(base + f.rel4[k]);
+    const uint32_t w0 = c[0] | (c[1] << 24);
+    const uint32_t w1 = (c[1] >> 8) | (c[2] << 16);
+    const uint32_t w2 = (c[2] >> 16) | (c[3] << 8);
+    const uint32_t w3 = c[4] | (c[5] << 24);
+    const uint32_t w4 = c[5] >> 8;
+    uint4 o;
+    o.x = (__builtin_amdgcn_alignbit(w1, w0, f.shift) & f.andm[0]) | f.orm[0];
+    o.y = (__builtin_amdgcn_alignbit(w2, w1, f.shift) & f.andm[1]) | f.orm[1];
+    o.z = (__builtin_amdgcn_alignbit(w3, w2, f.shift) & f.andm[2]) | f.orm[2];
+    o.w = (__builtin_amdgcn_alignbit(w4, w3, f.shift) & f.andm[3]) | f.orm[3];
+    *reinterpret_cast<uint4 *>(dst + 16 * lane) = o;
+}
+
+// ---------------------------------------------------------------- state matrix (env_buffer.py:300-318)
+__device__ __forceinline__ void emit_matrix_fast(const uint32_t *env, int ax, int ay, int lane, float *dst) {
     const int ca = ay * GS + ax;
-    for (int c = lane; c < NC; c += 64) {
-        const uint32_t ty = cells[c] & 0xffu;
-        float m = ty == 2u ? -0.9f : (ty == 6u ? -0.5f : 0.9f);
-        if (c == ca) m = 0.3f;
-        dst[c] = m;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int q = lane + 64 * pass;
+        if (q < MAT_WORDS / 4) {
+            uint4 v = *reinterpret_cast<const uint4 *>(env + MAT_OFF + 4 * q);
+            const int d = ca - 4 * q;
+            v.x = d == 0 ? M_AGENT : v.x;
+            v.y = d == 1 ? M_AGENT : v.y;
+            v.z = d == 2 ? M_AGENT : v.z;
+            v.w = d == 3 ? M_AGENT : v.w;
+            *reinterpret_cast<uint4 *>(dst + 4 * q) = v;
+        }
     }
 }
 
-__device__ __forceinline__ float reward_value(int code) {
-    return code == R_STEP ? -0.01f : code == R_RISK ? -0.1f : code == R_HIT ? -0.9f : code == R_ROOM2 ? 0.2f : 0.9f;
+__device__ __forceinline__ void emit_matrix_generic(const uint32_t *env, int ax, int ay, int lane, float *dst) {
+    const int ca = ay * GS + ax;
+    uint32_t *d = reinterpret_cast<uint32_t *>(dst);
+    for (int c = lane; c < NC; c += 64) d[c] = c == ca ? M_AGENT : env[MAT_OFF + c];
+}
+
+// (re)generate one env's LDS image interior cooperatively (auto-reset / init)
+__device__ __forceinline__ void regen_env(uint32_t *env, int lane) {
+    for (int c = lane; c < NC; c += 64) {
+        const int y = c / GS, x = c - y * GS;
+        const uint32_t code = gen_cell(x, y);
+        env[gpi(x, y)] = code;
+        env[MAT_OFF + c] = mat_of_code(code);
+    }
 }
 
 // ---------------------------------------------------------------- the rollout kernel
-__global__ __launch_bounds__(64) void tw_rollout_kernel(Params p) {
-    __shared__ uint32_t cells[NC + 3];
-    __shared__ uint32_t stage[(NC * 3 + 8) / 4 + 1];
-    __shared__ int32_t recs[REC];
+// FAST = every output present, native 16-byte layouts, actions supplied, Philox draws: all the
+// wave-uniform "is this pointer null / is this layout aligned" branches fold away at compile time.
+// Launch bounds: 4 waves per SIMD for E <= 2 (<= 128 VGPRs): at 4096 envs the grid is only 4096 / E
+// single-wave workgroups for 1024 SIMDs, and a lone wave issues a dependent instruction every
+// ~11 cycles, so residency (not instruction count) sets the step time.
+template <int E, int VARIANT, bool FAST>
+__global__ __launch_bounds__(64, (E == 1 ? 4 : 2)) void tw_rollout_kernel(Params p) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds_env[E * ENV_WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t stage[STAGE_WORDS];
+    __shared__ int32_t recs[E * REC];
+    __shared__ int32_t act_lds[64 * E];
 
-    const int n = blockIdx.x;
+    constexpr bool V4 = VARIANT == 4;
     const int lane = threadIdx.x;
     const int N = p.n_envs;
-    const uint32_t env_id = p.env_id0 + (uint32_t)n;
+    const int n0 = blockIdx.x * E;                      // first env of this wave
+    const int n_mine = n0 + lane;                       // env of this lane (logic phase)
+    const bool active = lane < E && n_mine < N;
+    const uint32_t env_id = p.env_id0 + (uint32_t)n_mine;
+    uint32_t *my_env = lds_env + (lane < E ? lane : 0) * ENV_WORDS;
 
-    if (lane < REC) recs[lane] = p.rec[(size_t)n * REC + lane];
-    for (int c = lane; c < NC; c += 64)
-        cells[c] = (uint32_t)p.type[(size_t)n * NC + c] | ((uint32_t)p.colour[(size_t)n * NC + c] << 8);
+    // ---- stage records and planes into LDS
+    for (int i = lane; i < E * REC; i += 64) {
+        const int e = i / REC;
+        recs[i] = (n0 + e < N) ? p.rec[(size_t)n0 * REC + i] : 0;
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        uint32_t *env = lds_env + e * ENV_WORDS;
+        for (int i = lane; i < GP_WORDS; i += 64) env[i] = C_WALL;          // wall padding
+        if (lane < MAT_WORDS - NC) env[MAT_OFF + NC + lane] = 0u;
+    }
+    wave_sync();
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (n0 + e >= N) break;
+        uint32_t *env = lds_env + e * ENV_WORDS;
+        const size_t gb = (size_t)(n0 + e) * NC;
+        for (int c = lane; c < NC; c += 64) {
+            const uint32_t code = (uint32_t)p.type[gb + c] | ((uint32_t)p.colour[gb + c] << 8);
+            const int y = c / GS, x = c - y * GS;
+            env[gpi(x, y)] = code;
+            env[MAT_OFF + c] = mat_of_code(code);
+        }
+    }
     wave_sync();
     EnvS s;
-    load_env(s, recs);
+    load_env(s, recs + (lane < E ? lane : 0) * REC);
 
     const int V = p.view;
-    const ViewIdx widx = make_view_idx(lane, V);
-    const size_t obs_bytes = (size_t)V * V * 3;
-    const bool v4 = p.variant == 4;
+    const int obs_chunk_bytes = ((V * V * 3 + 15) >> 4) << 4;
     const bool autoreset = (p.flags & TW_F_AUTORESET) != 0;
-    const bool policy_idx = (p.flags & TW_F_POLICY_IDX) != 0 || p.actions == nullptr;
+    const bool has_obs = FAST || p.obs != nullptr, has_mat = FAST || p.matrix != nullptr;
+    const bool has_actions = FAST || p.actions != nullptr, has_draws = !FAST && p.draws != nullptr;
+    const bool policy_idx = (p.flags & TW_F_POLICY_IDX) != 0 || !has_actions;
+    const bool fast_obs_ok = FAST || (p.obs && ((uintptr_t)p.obs & 15u) == 0 && (p.obs_pitch & 15) == 0 &&
+                                      p.obs_pitch >= obs_chunk_bytes);
+    const bool fast_mat_ok = FAST || (p.matrix && ((uintptr_t)p.matrix & 15u) == 0 && (p.mat_pitch & 3) == 0 &&
+                                      p.mat_pitch >= MAT_WORDS);
+    const ObsFast of = make_obs_fast(lane, V);
+    const bool layouts_fast = FAST || ((!p.obs || fast_obs_ok) && (!p.matrix || fast_mat_ok));
+    const unsigned long long m_active = __ballot(active);
 
-    int act_vec = 0;                                  // lane l: action of step (tt & ~63) + l
-    for (int tt = 0; tt < p.T; ++tt) {
-        const size_t idx = (size_t)tt * N + n;
-        if (p.actions && (tt & 63) == 0) {
-            const int ts = tt + lane;
-            act_vec = ts < p.T ? p.actions[(size_t)ts * N + n] : 0;
+    // running output cursors (advance by one time row per step)
+    uint8_t *obs_row = has_obs ? p.obs + (size_t)n0 * p.obs_pitch : nullptr;
+    float *mat_row = has_mat ? p.matrix + (size_t)n0 * p.mat_pitch : nullptr;
+    const size_t obs_step = (size_t)N * p.obs_pitch, mat_step = (size_t)N * p.mat_pitch;
+    size_t idx = (size_t)n0 + lane;                         // [t][n] row of this lane's env
+
+    for (int tt = 0; tt < p.T; ++tt, idx += N, obs_row += obs_step, mat_row += mat_step) {
+
+        // ---- actions: one coalesced-per-env vector load every 64 steps, parked in LDS
+        if (has_actions && (tt & 63) == 0) {
+            wave_sync();
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int ts = tt + lane;
+                act_lds[lane * E + e] = (ts < p.T && n0 + e < N) ? p.actions[(size_t)ts * N + n0 + e] : 0;
+            }
+            wave_sync();
         }
-        const uint32_t t = s.t;
-        const uint32_t *dr = p.draws ? p.draws + idx * TW_DRAW_WORDS : nullptr;
-        auto take = [&](uint32_t slot) -> uint32_t {
-            return dr ? (uint32_t)rfl((int)dr[slot]) : draw_word(p.seed_lo, p.seed_hi, env_id, t, slot);
-        };
 
-        int action;
-        if (p.actions) action = __builtin_amdgcn_readlane(act_vec, tt & 63);
-        else action = (int)(draw_word(p.seed_lo, p.seed_hi, env_id, t, TW_S_ACTION) % 5u);
-        if (policy_idx && action == 4) action = 6;                // Env_transact.env_action
-
-        // ================= part 1: pre-observation transition
-        s.t += 1;
-        int err = TW_ENV_OK;
-        int terminated = 0, truncated = 0, reward = R_STEP;
-        bool have_obs = false;
-        do {
+        // ================= LOGIC part 1 (lane-per-env): everything before gen_obs()
+        int err = TW_ENV_OK, have_obs = 0, terminated = 0, truncated = 0, reward = R_STEP;
+        uint32_t dw[4] = {0, 0, 0, 0};                      // draw block 0: gate, wall1, wall2, spawn
+        const uint32_t t_now = s.t;
+        if (active) {
+            int action;
+            if (has_actions) action = act_lds[(tt & 63) * E + lane];
+            else {
+                uint32_t w[4];
+                draw_block(p.seed_lo, p.seed_hi, env_id, t_now, 2, w);
+                action = (int)(w[0] % 5u);
+            }
+            if (policy_idx && action == 4) action = 6;            // Env_transact.env_action
+            if (V4) {
+                if (has_draws) {
+                    const uint32_t *dr = p.draws + idx * TW_DRAW_WORDS;
+                    dw[0] = dr[0]; dw[1] = dr[1]; dw[2] = dr[2]; dw[3] = dr[3];
+                } else {
+                    draw_block(p.seed_lo, p.seed_hi, env_id, t_now, 0, dw);
+                }
+            }
+            s.t += 1;
             if (action >= 7) action = 0;                          // twoarmy_v6.py:85-86
             s.step_move += 1;                                     // :88
-            const int sm = s.step_move;
-            const int m6 = sm % 6;
-            // row-8 balls (:96-112): clear all, then put each inside try/except
-            bool ok = true;
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-                if (ok && !set_cell(cells, lane, s.obx[k], s.oby[k], C_EMPTY)) ok = false;
-            if (!ok) { err = TW_ENV_ASSERT; break; }
-            const int dxb = (m6 == 1 || m6 == 0) ? 1 : ((m6 == 2 || m6 == 3) ? -1 : 0);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int nx = s.obx[k] + dxb;
-                if (set_cell(cells, lane, nx, 8, C_BALL)) { s.obx[k] = nx; s.oby[k] = 8; }
-            }
-            if (v4) {
-                if (s.upd_long) {                                 // twoarmy_v4.py:115-144
-                    s.upd_horiz = 0;
-                    bool go = (sm % 4 == 2) || (m6 == 3) || (m6 == 0);
-                    if (!go) go = (take(TW_S_GATE) % 10u) == 6u;
-                    if (go && s.patrol) {
-                        if (s.up1) {
-                            if (!move_group<3>(cells, lane, s.o1x, s.o1y, s.o1v, 0, -1, err)) break;
-                            if (s.o1y[0] == 3) s.up1 = 0;
-                        } else {
-                            if (!move_group<3>(cells, lane, s.o1x, s.o1y, s.o1v, 0, 1, err)) break;
-                            if (s.o1y[2] == 7) s.up1 = 1;
-                        }
-                    }
-                }
-                if (s.upd_horiz) {                                // twoarmy_v4.py:147-176
-                    s.upd_long = 0;
-                    bool go = (m6 != 1);
-                    if (!go) go = (take(TW_S_GATE) % 10u) == 6u;
-                    if (go && s.patrol) {
-                        if (s.right2) {
-                            if (!move_group<4>(cells, lane, s.o2x, s.o2y, s.o2v, 1, 0, err)) break;
-                            if (s.o2x[3] == 11) s.right2 = 0;
-                        } else {
-                            if (!move_group<4>(cells, lane, s.o2x, s.o2y, s.o2v, -1, 0, err)) break;
-                            if (s.o2x[0] == 5) s.right2 = 1;
-                        }
-                    }
-                }
-            }
-            // ---- MiniGridEnv.step (minigrid.py:1333-1441)
-            s.step_count += 1;
-            {   // front_pos is read for every action (:1341-1344): bounds assert
-                const int fx = s.ax + (s.dir == 0 ? 1 : (s.dir == 2 ? -1 : 0));
-                const int fy = s.ay + (s.dir == 1 ? 1 : (s.dir == 3 ? -1 : 0));
-                if (!inb(fx, fy)) { err = TW_ENV_ASSERT; break; }
-            }
-            int tx = s.ax, ty = s.ay;
-            if (action == 0) tx -= 1;
-            else if (action == 1) tx += 1;
-            else if (action == 2) ty -= 1;
-            else if (action == 3) ty += 1;
-            else if (action != 6) { err = TW_ENV_ATTRIBUTE; break; }   // self.actions.forward, :1397
-            if (!inb(tx, ty)) { err = TW_ENV_ASSERT; break; }
-            wave_sync();                                      // lane-0 cell writes -> all lanes
-            {
-                const uint32_t cv = (uint32_t)rfl((int)cells[ty * GS + tx]);
-                const uint32_t ct = cv & 0xffu, cs = (cv >> 16) & 0xffu;
-                const bool overlap = ct == 8u || ct == 11u || ct == 3u || ct == 9u || (ct == 4u && cs == 0u);
-                if (ct == 1u || overlap) { s.ax = tx; s.ay = ty; }
-                if (ct == 8u) terminated = 1;
-            }
-            if (s.step_count >= s.max_steps) truncated = 1;       // :1436-1437
-            have_obs = true;
-        } while (false);
-
-        if (!have_obs) {           // the reference raised: state keeps the mutations made so far
-            s.err = err;
-            s.last_reward = -1; s.last_term = 0; s.last_trunc = 0;
-            wave_sync();
-            continue;
-        }
-
-        // ================= observation (before wall drop / spawn of the same step)
-        if (p.obs) emit_obs(cells, stage, lane, V, s.ax, s.ay, s.dir, p.obs + idx * obs_bytes, widx);
-
-        // ================= part 2: post-observation logic
-        do {
-            if (!s.pone && (s.ax > 3 || s.ay < 14)) {             // twoarmy_v6.py:182-198 / v4:181-195
-                int i1 = 11, i2 = 8;
-                if (v4) {
-                    i1 = 9 + (int)(take(TW_S_WALL1) % 4u);
-                    i2 = 6 + (int)(take(TW_S_WALL2) % 4u);
-                }
-                if (lane < 8) {
-                    const int q = lane & 3, blk = lane >> 2;       // 2x2 blocks
-                    const int x = blk == 0 ? 4 + (q & 1) : i2 + (q >> 1);
-                    const int y = blk == 0 ? i1 + (q >> 1) : 11 + (q & 1);
-                    cells[y * GS + x] = C_WALL;
-                }
-                s.pone = 1;
-            }
-            if (v4 && !s.patrol && s.ay <= 8) {                   // twoarmy_v4.py:212-225
-                const int i = 6 + (int)(take(TW_S_SPAWN) % 4u);
-                s.o2x[0] = i; s.o2x[1] = i + 1; s.o2x[2] = i; s.o2x[3] = i + 1;
-                s.o2y[0] = 4; s.o2y[1] = 4; s.o2y[2] = 5; s.o2y[3] = 5;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { s.o1x[k] = 12; s.o1y[k] = 4 + k; }
-                if (lane < 7) {
-                    const int x = lane < 4 ? i + (lane & 1) : 12;
-                    const int y = lane < 4 ? 4 + (lane >> 1) : lane;   // lanes 4,5,6 -> y 4,5,6
-                    cells[y * GS + x] = C_BALL;
-                }
-                s.o1v = 1; s.o2v = 1; s.patrol = 1;
-            }
-            // row-ball collision / proximity (twoarmy_v6.py:231-243)
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-                if (s.ax == s.obx[k] && s.ay == s.oby[k]) { reward = R_HIT; truncated = 1; }
-            if (s.ay == s.oby[0] + 1 && (s.ax == s.obx[0] || s.ax == s.obx[1] || s.ax == s.obx[2])) reward = R_RISK;
-            if (s.patrol) {                                       // :245-283
-                if (!s.o1v || !s.o2v) { err = TW_ENV_TYPE; break; }
-                if (s.ay == s.o2y[2] + 1 && (s.ax == s.o2x[2] || s.ax == s.o2x[3])) reward = R_RISK;
-                if (s.ax == s.o2x[0] - 1 && (s.ay == s.o2y[0] || s.ay == s.o2y[2])) reward = R_RISK;
-                if (s.ax == s.o2x[1] + 1 && (s.ay == s.o2y[1] || s.ay == s.o2y[3])) reward = R_RISK;
-                if (s.ax == s.o1x[0] - 1 && (s.ay == s.o1y[0] || s.ay == s.o1y[1] || s.ay == s.o1y[2])) reward = R_RISK;
+            s.m6 = s.m6 == 5 ? 0 : s.m6 + 1;
+            s.m4 = (s.m4 + 1) & 3;
+            const int m6 = s.m6;
+            const int dxb = (m6 <= 1) ? 1 : (m6 <= 3 ? -1 : 0);   // :104-109
+            bool alive = true;
+            // ---- row-8 balls (:96-112): clear all three, then put each inside try/except.
+            // Fast path (always taken in normal play): the balls are the adjacent triple b..b+2 on row 8
+            // and the moved triple stays inside the grid -> 4 branch-free cell writes.
+            const int b0 = s.obx[0];
+            const bool balls_fast = (s.oby[0] == 8) & (s.oby[1] == 8) & (s.oby[2] == 8) & (s.obx[1] == b0 + 1) &
+                                    (s.obx[2] == b0 + 2) & ((unsigned)(b0 + dxb - 1) <= 12u) & ((unsigned)(b0 - 1) <= 12u);
+            if (balls_fast) {
+                uint32_t *row8 = my_env + gpi(0, 8);
+                uint32_t *mrow8 = my_env + MAT_OFF + 8 * GS;
+                const int nb = b0 + dxb;
+                const int cx = dxb > 0 ? b0 : b0 + 2;             // the vacated cell (a ball cell when dxb == 0)
+                row8[cx] = dxb != 0 ? C_EMPTY : C_BALL;
+                mrow8[cx] = dxb != 0 ? M_FREE : M_BALL;
+                row8[nb] = C_BALL; row8[nb + 1] = C_BALL; row8[nb + 2] = C_BALL;
+                mrow8[nb] = M_BALL; mrow8[nb + 1] = M_BALL; mrow8[nb + 2] = M_BALL;
+                s.obx[0] = nb; s.obx[1] = nb + 1; s.obx[2] = nb + 2;
+            } else {
+                bool ok = true;
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
-                    if (s.ax == s.o1x[k] && s.ay == s.o1y[k]) { reward = R_HIT; truncated = 1; }
+                    if (ok) { if (inb(s.obx[k], s.oby[k])) put(my_env, s.obx[k], s.oby[k], C_EMPTY, M_FREE); else ok = false; }
+                if (!ok) { err = TW_ENV_ASSERT; alive = false; }
+                else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (s.ax == s.o2x[k] && s.ay == s.o2y[k]) { reward = R_HIT; truncated = 1; }
+                    for (int k = 0; k < 3; ++k) {
+                        const int nx = s.obx[k] + dxb;
+                        if (inb(nx, 8)) { put(my_env, nx, 8, C_BALL, M_BALL); s.obx[k] = nx; s.oby[k] = 8; }
+                    }
+                }
             }
-            if (s.first_room2 && s.ay == 7) { reward = R_ROOM2; s.first_room2 = 0; }   // :285-288
-            if (reward == R_RISK) {                               // :290-294
-                s.risk += 1;
-                if (s.risk > 5) truncated = 1;
+            if (V4 && alive) {
+                if (s.upd_long) {                                 // twoarmy_v4.py:115-144
+                    s.upd_horiz = 0;
+                    bool go = (s.m4 == 2) || (m6 == 3) || (m6 == 0);
+                    if (!go) go = (dw[TW_S_GATE] % 10u) == 6u;
+                    if (go && s.patrol) {
+                        if (s.up1) {
+                            alive = move_group<3>(my_env, s.o1x, s.o1y, s.o1v, 0, -1, err);
+                            if (alive && s.o1y[0] == 3) s.up1 = 0;
+                        } else {
+                            alive = move_group<3>(my_env, s.o1x, s.o1y, s.o1v, 0, 1, err);
+                            if (alive && s.o1y[2] == 7) s.up1 = 1;
+                        }
+                    }
+                }
+                if (alive && s.upd_horiz) {                       // twoarmy_v4.py:147-176
+                    s.upd_long = 0;
+                    bool go = (m6 != 1);
+                    if (!go) go = (dw[TW_S_GATE] % 10u) == 6u;
+                    if (go && s.patrol) {
+                        if (s.right2) {
+                            alive = move_group<4>(my_env, s.o2x, s.o2y, s.o2v, 1, 0, err);
+                            if (alive && s.o2x[3] == 11) s.right2 = 0;
+                        } else {
+                            alive = move_group<4>(my_env, s.o2x, s.o2y, s.o2v, -1, 0, err);
+                            if (alive && s.o2x[0] == 5) s.right2 = 1;
+                        }
+                    }
+                }
             }
-            if (terminated || truncated) {                        // :296-318
-                if (terminated) reward = R_GOAL;
-                s.step_move = 0; s.pone = 0; s.patrol = 0; s.first_room2 = 1; s.risk = 0;
-                if ((take(TW_S_COIN_A) & 1u) == 1u) { s.up1 = 0; s.right2 = 1; } else { s.up1 = 1; s.right2 = 0; }
-                if ((take(TW_S_COIN_B) & 1u) == 1u) { s.upd_horiz = 0; s.upd_long = 1; } else { s.upd_horiz = 1; s.upd_long = 0; }
-                s.episodes += 1;
+            if (alive) {
+                // ---- MiniGridEnv.step (minigrid.py:1333-1441)
+                s.step_count += 1;
+                const int tx = s.ax + (action == 1) - (action == 0);
+                const int ty = s.ay + (action == 3) - (action == 2);
+                // fast path: legal action, facing up, agent strictly inside the border -> front_pos and the
+                // target cell are in bounds, nothing can raise
+                const bool move_fast = (((unsigned)action <= 3u) | (action == 6)) & (s.dir == 3) &
+                                       ((unsigned)(s.ax - 1) <= 14u) & ((unsigned)(s.ay - 1) <= 14u);
+                bool legal = move_fast;
+                if (!move_fast) {
+                    const int fx = s.ax + (s.dir == 0 ? 1 : (s.dir == 2 ? -1 : 0));   // front_pos (:1341-1344)
+                    const int fy = s.ay + (s.dir == 1 ? 1 : (s.dir == 3 ? -1 : 0));
+                    if (!inb(fx, fy)) err = TW_ENV_ASSERT;
+                    else if (action > 3 && action != 6) err = TW_ENV_ATTRIBUTE;   // self.actions.forward, :1397
+                    else if (action < 0) err = TW_ENV_ATTRIBUTE;
+                    else if (!inb(tx, ty)) err = TW_ENV_ASSERT;
+                    else legal = true;
+                }
+                if (legal) {
+                    const uint32_t cv = my_env[gpi(tx, ty)];
+                    const uint32_t ct = cv & 0xffu, cs = (cv >> 16) & 0xffu;
+                    // empty(1) or can_overlap: floor 3, goal 8, lava 9, subgoal 11, open door (4, state 0)
+                    const bool enter = ((ct < 12u) & ((0x0B0Au >> (ct & 15u)) & 1u)) | ((ct == 4u) & (cs == 0u));
+                    s.ax = enter ? tx : s.ax;
+                    s.ay = enter ? ty : s.ay;
+                    terminated = ct == 8u;
+                    truncated = s.step_count >= s.max_steps;      // :1436-1437
+                    have_obs = 1;
+                }
             }
-        } while (false);
-        s.err = err;
-        if (err != TW_ENV_OK) {
-            s.last_reward = -1; s.last_term = 0; s.last_trunc = 0;
-            wave_sync();
-            continue;
-        }
-        s.last_reward = reward; s.last_term = terminated; s.last_trunc = truncated;
-        wave_sync();                                          // wall / spawn cell writes -> all lanes
-
-        // ================= outputs after the full step
-        if (p.matrix) emit_matrix(cells, lane, s.ax, s.ay, p.matrix + idx * NC);
-        if (lane == 0) {
-            if (p.reward) p.reward[idx] = reward_value(reward);
-            if (p.term) p.term[idx] = (uint8_t)terminated;
-            if (p.trunc) p.trunc[idx] = (uint8_t)truncated;
-        }
-        if (p.pos && lane < 2) p.pos[idx * 2 + lane] = (float)(lane == 0 ? s.ay : s.ax);
-
-        // ================= auto-reset (soa/train_ppo.py:104: reset() opens every episode)
-        if (autoreset && (terminated || truncated)) {
-            wave_sync();
-            for (int c = lane; c < NC; c += 64) {
-                const int y = c / GS, x = c - y * GS;
-                cells[c] = gen_cell(x, y);
+            if (!have_obs) {       // the reference raised: state keeps the mutations made so far
+                s.err = err; s.last_reward = -1; s.last_term = 0; s.last_trunc = 0;
             }
-            reset_scalars(s);
         }
         wave_sync();
+
+        // ================= LOGIC part 2 (lane-per-env): everything after gen_obs().
+        // CELLS=false is the common case in which no lane drops walls / spawns patrols / raises this
+        // step, so part 2 touches no LDS cell and may be scheduled among the emission loads.
+        int done = 0;
+        auto part2 = [&](auto cells_tag) {
+            constexpr bool CELLS = decltype(cells_tag)::value;
+            if (!(active && have_obs)) return;
+            if (CELLS) {
+                if (!s.pone && (s.ax > 3 || s.ay < 14)) {         // twoarmy_v6.py:182-198 / v4:181-195
+                    int i1 = 11, i2 = 8;
+                    if (V4) { i1 = 9 + (int)(dw[TW_S_WALL1] % 4u); i2 = 6 + (int)(dw[TW_S_WALL2] % 4u); }
+                    put(my_env, 4, i1, C_WALL, M_WALL); put(my_env, 5, i1, C_WALL, M_WALL);
+                    put(my_env, 4, i1 + 1, C_WALL, M_WALL); put(my_env, 5, i1 + 1, C_WALL, M_WALL);
+                    put(my_env, i2, 11, C_WALL, M_WALL); put(my_env, i2, 12, C_WALL, M_WALL);
+                    put(my_env, i2 + 1, 11, C_WALL, M_WALL); put(my_env, i2 + 1, 12, C_WALL, M_WALL);
+                    s.pone = 1;
+                }
+                if (V4 && !s.patrol && s.ay <= 8) {               // twoarmy_v4.py:212-225
+                    const int i = 6 + (int)(dw[TW_S_SPAWN] % 4u);
+                    s.o2x[0] = i; s.o2x[1] = i + 1; s.o2x[2] = i; s.o2x[3] = i + 1;
+                    s.o2y[0] = 4; s.o2y[1] = 4; s.o2y[2] = 5; s.o2y[3] = 5;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) put(my_env, s.o2x[k], s.o2y[k], C_BALL, M_BALL);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { s.o1x[k] = 12; s.o1y[k] = 4 + k; put(my_env, 12, 4 + k, C_BALL, M_BALL); }
+                    s.o1v = 1; s.o2v = 1; s.patrol = 1;
+                }
+            }
+            // row-ball collision / proximity (twoarmy_v6.py:231-243), branch-free
+            bool hit = false, risk = false;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) hit |= (s.ax == s.obx[k]) & (s.ay == s.oby[k]);
+            risk = (s.ay == s.oby[0] + 1) & ((s.ax == s.obx[0]) | (s.ax == s.obx[1]) | (s.ax == s.obx[2]));
+            reward = hit ? R_HIT : reward;
+            reward = risk ? R_RISK : reward;
+            if (s.patrol) {                                       // :245-283 (dead in v6: patrol is never set)
+                if (CELLS && (!s.o1v || !s.o2v)) err = TW_ENV_TYPE;
+                else {
+                    bool prisk = (s.ay == s.o2y[2] + 1) & ((s.ax == s.o2x[2]) | (s.ax == s.o2x[3]));
+                    prisk |= (s.ax == s.o2x[0] - 1) & ((s.ay == s.o2y[0]) | (s.ay == s.o2y[2]));
+                    prisk |= (s.ax == s.o2x[1] + 1) & ((s.ay == s.o2y[1]) | (s.ay == s.o2y[3]));
+                    prisk |= (s.ax == s.o1x[0] - 1) & ((s.ay == s.o1y[0]) | (s.ay == s.o1y[1]) | (s.ay == s.o1y[2]));
+                    bool phit = false;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) phit |= (s.ax == s.o1x[k]) & (s.ay == s.o1y[k]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) phit |= (s.ax == s.o2x[k]) & (s.ay == s.o2y[k]);
+                    reward = prisk ? R_RISK : reward;
+                    reward = phit ? R_HIT : reward;
+                    hit |= phit;
+                }
+            }
+            truncated |= hit;
+            if (!CELLS || err == TW_ENV_OK) {
+                const bool room2 = s.first_room2 & (s.ay == 7);   // :285-288
+                reward = room2 ? R_ROOM2 : reward;
+                s.first_room2 = room2 ? 0 : s.first_room2;
+                s.risk += (reward == R_RISK);                     // :290-294
+                truncated |= (reward == R_RISK) & (s.risk > 5);
+                if (terminated || truncated) {                    // :296-318
+                    if (terminated) reward = R_GOAL;
+                    s.step_move = 0; s.m6 = 0; s.m4 = 0;
+                    s.pone = 0; s.patrol = 0; s.first_room2 = 1; s.risk = 0;
+                    uint32_t cw[4];
+                    if (has_draws) {
+                        const uint32_t *dr = p.draws + idx * TW_DRAW_WORDS;
+                        cw[0] = dr[TW_S_COIN_A]; cw[1] = dr[TW_S_COIN_B];
+                    } else {
+                        draw_block(p.seed_lo, p.seed_hi, env_id, t_now, 1, cw);
+                    }
+                    if ((cw[0] & 1u) == 1u) { s.up1 = 0; s.right2 = 1; } else { s.up1 = 1; s.right2 = 0; }
+                    if ((cw[1] & 1u) == 1u) { s.upd_horiz = 0; s.upd_long = 1; } else { s.upd_horiz = 1; s.upd_long = 0; }
+                    s.episodes += 1;
+                    done = 1;
+                }
+                s.last_reward = reward; s.last_term = terminated; s.last_trunc = truncated;
+                if (FAST || p.reward) p.reward[idx] = reward_value(reward);
+                if (FAST || p.term) p.term[idx] = (uint8_t)terminated;
+                if (FAST || p.trunc) p.trunc[idx] = (uint8_t)truncated;
+                if (FAST || p.pos) { float2 ps; ps.x = (float)s.ay; ps.y = (float)s.ax; reinterpret_cast<float2 *>(p.pos)[idx] = ps; }
+            } else {
+                s.last_reward = -1; s.last_term = 0; s.last_trunc = 0;
+                have_obs = 0;                                     // no post-step outputs for a raised step
+            }
+            s.err = err;
+        };
+
+        // ---- wave-uniform path selection
+        const bool cells2 = active && have_obs &&
+                            ((!s.pone && (s.ax > 3 || s.ay < 14)) || (V4 && !s.patrol && s.ay <= 8) ||
+                             (s.patrol && (!s.o1v || !s.o2v)));
+        const bool common = layouts_fast && __ballot(active && have_obs && s.dir == 3) == m_active &&
+                            __ballot(cells2) == 0ull;
+        if (common) {
+            // ================= COMMON PATH: all gathers first, part 2 in their shadow, then pack + store
+            uint32_t oc[E][6];
+            uint4 mq[E][2];
+            int cax[E], cay[E];
+            const int qb = lane < 9 ? 64 + lane : 72;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                cax[e] = __builtin_amdgcn_readlane(s.ax, e);
+                cay[e] = __builtin_amdgcn_readlane(s.ay, e);
+                const uint32_t *env = lds_env + e * ENV_WORDS;
+                const char *base = reinterpret_cast<const char *>(env + gpi(cax[e], cay[e]));
+                if (has_obs) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) oc[e][k] = *reinterpret_cast<const uint32_t *>(base + of.rel4[k]);
+                }
+                if (has_mat) {
+                    mq[e][0] = *reinterpret_cast<const uint4 *>(env + MAT_OFF + 4 * lane);
+                    mq[e][1] = *reinterpret_cast<const uint4 *>(env + MAT_OFF + 4 * qb);
+                }
+            }
+            part2(std::false_type{});
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const bool valid_e = n0 + e < N;
+                if (has_obs) {
+                    const uint32_t *c = oc[e];
+                    const uint32_t w0 = c[0] | (c[1] << 24);
+                    const uint32_t w1 = (c[1] >> 8) | (c[2] << 16);
+                    const uint32_t w2 = (c[2] >> 16) | (c[3] << 8);
+                    const uint32_t w3 = c[4] | (c[5] << 24);
+                    const uint32_t w4 = c[5] >> 8;
+                    uint4 o;
+                    o.x = (__builtin_amdgcn_alignbit(w1, w0, of.shift) & of.andm[0]) | of.orm[0];
+                    o.y = (__builtin_amdgcn_alignbit(w2, w1, of.shift) & of.andm[1]) | of.orm[1];
+                    o.z = (__builtin_amdgcn_alignbit(w3, w2, of.shift) & of.andm[2]) | of.orm[2];
+                    o.w = (__builtin_amdgcn_alignbit(w4, w3, of.shift) & of.andm[3]) | of.orm[3];
+                    if (of.active && valid_e)
+                        *reinterpret_cast<uint4 *>(obs_row + (size_t)e * p.obs_pitch + 16 * lane) = o;
+                }
+                if (has_mat) {
+                    const int ca = cay[e] * GS + cax[e];
+                    float *dst = mat_row + (size_t)e * p.mat_pitch;
+#pragma unroll
+                    for (int pass = 0; pass < 2; ++pass) {
+                        const int q = pass == 0 ? lane : qb;
+                        uint4 v = mq[e][pass];
+                        const int d = ca - 4 * q;
+                        v.x = d == 0 ? M_AGENT : v.x;
+                        v.y = d == 1 ? M_AGENT : v.y;
+                        v.z = d == 2 ? M_AGENT : v.z;
+                        v.w = d == 3 ? M_AGENT : v.w;
+                        if (valid_e && (pass == 0 || lane < 9)) *reinterpret_cast<uint4 *>(dst + 4 * q) = v;
+                    }
+                }
+            }
+        } else {
+            // ================= ORDERED PATH: obs -> part 2 (cell writes) -> matrix, per-env generic fallbacks
+            if (has_obs) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if (!__builtin_amdgcn_readlane(have_obs, e)) continue;
+                    const int ax = __builtin_amdgcn_readlane(s.ax, e), ay = __builtin_amdgcn_readlane(s.ay, e);
+                    const int dir = __builtin_amdgcn_readlane(s.dir, e);
+                    const uint32_t *env = lds_env + e * ENV_WORDS;
+                    uint8_t *dst = obs_row + (size_t)e * p.obs_pitch;
+                    if (fast_obs_ok && dir == 3) emit_obs_fast(env, ax, ay, of, lane, dst);
+                    else emit_obs_generic([env](int x, int y) { return env[gpi(x, y)]; }, stage, lane, V, ax, ay, dir, dst);
+                }
+            }
+            part2(std::true_type{});
+            wave_sync();
+            if (has_mat) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if (!__builtin_amdgcn_readlane(have_obs, e)) continue;
+                    const int ax = __builtin_amdgcn_readlane(s.ax, e), ay = __builtin_amdgcn_readlane(s.ay, e);
+                    const uint32_t *env = lds_env + e * ENV_WORDS;
+                    float *dst = mat_row + (size_t)e * p.mat_pitch;
+                    if (fast_mat_ok) emit_matrix_fast(env, ax, ay, lane, dst);
+                    else emit_matrix_generic(env, ax, ay, lane, dst);
+                }
+            }
+        }
+
+        // ================= auto-reset (soa/train_ppo.py:104): ballot of done envs, regenerate in place
+        if (autoreset) {
+            const unsigned long long dm = __ballot(done != 0);
+            if (dm) {
+                wave_sync();
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    if ((dm >> e) & 1ull) regen_env(lds_env + e * ENV_WORDS, lane);
+                if (done) reset_scalars(s);
+                wave_sync();
+            }
+        }
     }
 
-    // write state back
-    if (lane == 0) store_env(s, recs);
+    // ---- write state back
     wave_sync();
-    if (lane < REC) p.rec[(size_t)n * REC + lane] = recs[lane];
-    for (int c = lane; c < NC; c += 64) {
-        const uint32_t v = cells[c];
-        p.type[(size_t)n * NC + c] = (uint8_t)v;
-        p.colour[(size_t)n * NC + c] = (uint8_t)(v >> 8);
+    if (lane < E) store_env(s, recs + lane * REC);
+    wave_sync();
+    for (int i = lane; i < E * REC; i += 64) {
+        const int e = i / REC;
+        if (n0 + e < N) p.rec[(size_t)n0 * REC + i] = recs[i];
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (n0 + e >= N) break;
+        const uint32_t *env = lds_env + e * ENV_WORDS;
+        const size_t gb = (size_t)(n0 + e) * NC;
+        for (int c = lane; c < NC; c += 64) {
+            const int y = c / GS, x = c - y * GS;
+            const uint32_t v = env[gpi(x, y)];
+            p.type[gb + c] = (uint8_t)v;
+            p.colour[gb + c] = (uint8_t)(v >> 8);
+        }
     }
 }
 
-// ---------------------------------------------------------------- init / reset / obs-only kernels
+// ---------------------------------------------------------------- init / reset / obs-only kernels (wave per env)
 // mode 0: Twoarmy __init__ (flags armed, twoarmy_v6.py:15-25) + reset;  mode 1: MiniGridEnv.reset only.
 __global__ __launch_bounds__(64) void tw_reset_kernel(Params p, const uint8_t *mask, int mode) {
     __shared__ uint32_t cells[NC + 3];
-    __shared__ uint32_t stage[(NC * 3 + 8) / 4 + 1];
+    __shared__ uint32_t stage[STAGE_WORDS];
     const int n = blockIdx.x, lane = threadIdx.x;
     if (mask && !mask[n]) return;
     int32_t *r = p.rec + (size_t)n * REC;
@@ -528,21 +822,26 @@ __global__ __launch_bounds__(64) void tw_reset_kernel(Params p, const uint8_t *m
         p.type[(size_t)n * NC + c] = (uint8_t)v;
         p.colour[(size_t)n * NC + c] = (uint8_t)(v >> 8);
     }
-    __syncthreads();
-    if (p.obs) emit_obs(cells, stage, lane, p.view, 3, 15, 3, p.obs + (size_t)n * p.view * p.view * 3,
-                        make_view_idx(lane, p.view));
+    wave_sync();
+    const uint32_t *cc = cells;
+    if (p.obs)
+        emit_obs_generic([cc](int x, int y) { return cc[y * GS + x]; }, stage, lane, p.view, 3, 15, 3,
+                         p.obs + (size_t)n * p.obs_pitch);
 }
 
 __global__ __launch_bounds__(64) void tw_gen_obs_kernel(Params p) {
     __shared__ uint32_t cells[NC + 3];
-    __shared__ uint32_t stage[(NC * 3 + 8) / 4 + 1];
+    __shared__ uint32_t stage[STAGE_WORDS];
     const int n = blockIdx.x, lane = threadIdx.x;
     for (int c = lane; c < NC; c += 64)
         cells[c] = (uint32_t)p.type[(size_t)n * NC + c] | ((uint32_t)p.colour[(size_t)n * NC + c] << 8);
-    __syncthreads();
+    wave_sync();
     const int32_t *r = p.rec + (size_t)n * REC;
-    emit_obs(cells, stage, lane, p.view, rfl(r[TW_AX]), rfl(r[TW_AY]), rfl(r[TW_DIR]),
-             p.obs + (size_t)n * p.view * p.view * 3, make_view_idx(lane, p.view));
+    const int ax = __builtin_amdgcn_readfirstlane(r[TW_AX]), ay = __builtin_amdgcn_readfirstlane(r[TW_AY]);
+    const int dir = __builtin_amdgcn_readfirstlane(r[TW_DIR]);
+    const uint32_t *cc = cells;
+    emit_obs_generic([cc](int x, int y) { return cc[y * GS + x]; }, stage, lane, p.view, ax, ay, dir,
+                     p.obs + (size_t)n * p.obs_pitch);
 }
 
 __global__ void tw_fill_actions_kernel(Params p, int32_t *out) {
@@ -551,7 +850,9 @@ __global__ void tw_fill_actions_kernel(Params p, int32_t *out) {
     if (i >= total) return;
     const int tt = i / p.n_envs, n = i - tt * p.n_envs;
     const uint32_t t = (uint32_t)p.rec[(size_t)n * REC + TW_T] + (uint32_t)tt;
-    out[i] = (int32_t)(draw_word(p.seed_lo, p.seed_hi, p.env_id0 + (uint32_t)n, t, TW_S_ACTION) % 5u);
+    uint32_t w[4];
+    draw_block(p.seed_lo, p.seed_hi, p.env_id0 + (uint32_t)n, t, 2, w);
+    out[i] = (int32_t)(w[0] % 5u);
 }
 
 int g_last_hip_error = 0;
@@ -566,6 +867,7 @@ struct tw_engine {
     uint32_t env_id0;
     uint8_t *type, *colour;
     int32_t *rec;
+    int envs_per_wave;      // 0 = auto
 };
 
 namespace {
@@ -596,18 +898,55 @@ Params base_params(const tw_engine *e) {
     p.seed_lo = (uint32_t)e->seed; p.seed_hi = (uint32_t)(e->seed >> 32);
     p.env_id0 = e->env_id0;
     p.T = 1;
+    p.obs_pitch = e->view * e->view * 3;
+    p.mat_pitch = NC;
     return p;
 }
 
 bool view_ok(int v) { return v >= 3 && v <= GS && (v & 1); }
 
-int launch_rollout(tw_engine *e, int T, const int32_t *actions, const uint32_t *draws, uint8_t *obs,
-                   float *matrix, float *pos, float *reward, uint8_t *term, uint8_t *trunc, int flags,
+// envs per wavefront: amortise the lane-per-env logic while keeping >= ~2 waves per SIMD (1024 SIMDs)
+int pick_envs_per_wave(const tw_engine *e) {
+    if (e->envs_per_wave > 0) return e->envs_per_wave;
+    if (e->n_envs >= 2048) return 2;       // measured best at 4096 envs on MI355X
+    return 1;
+}
+
+bool params_fast(const tw_engine *e, const Params &p) {
+    const int chunk = ((e->view * e->view * 3 + 15) >> 4) << 4;
+    return p.obs && p.matrix && p.pos && p.reward && p.term && p.trunc && p.actions && !p.draws &&
+           ((uintptr_t)p.obs & 15u) == 0 && (p.obs_pitch & 15) == 0 && p.obs_pitch >= chunk &&
+           ((uintptr_t)p.matrix & 15u) == 0 && (p.mat_pitch & 3) == 0 && p.mat_pitch >= MAT_WORDS;
+}
+
+template <int E>
+void launch_variant(const tw_engine *e, const Params &p, hipStream_t st) {
+    const int grid = (e->n_envs + E - 1) / E;
+    const bool fast = params_fast(e, p);
+    if (e->variant == 4) {
+        if (fast) hipLaunchKernelGGL((tw_rollout_kernel<E, 4, true>), dim3(grid), dim3(64), 0, st, p);
+        else hipLaunchKernelGGL((tw_rollout_kernel<E, 4, false>), dim3(grid), dim3(64), 0, st, p);
+    } else {
+        if (fast) hipLaunchKernelGGL((tw_rollout_kernel<E, 6, true>), dim3(grid), dim3(64), 0, st, p);
+        else hipLaunchKernelGGL((tw_rollout_kernel<E, 6, false>), dim3(grid), dim3(64), 0, st, p);
+    }
+}
+
+int launch_rollout(tw_engine *e, int T, const int32_t *actions, const uint32_t *draws, uint8_t *obs, int obs_pitch,
+                   float *matrix, int mat_pitch, float *pos, float *reward, uint8_t *term, uint8_t *trunc, int flags,
                    hipStream_t st) {
     Params p = base_params(e);
     p.T = T; p.actions = actions; p.draws = draws; p.obs = obs; p.matrix = matrix; p.pos = pos;
     p.reward = reward; p.term = term; p.trunc = trunc; p.flags = flags;
-    hipLaunchKernelGGL(tw_rollout_kernel, dim3(e->n_envs), dim3(64), 0, st, p);
+    if (obs_pitch > 0) p.obs_pitch = obs_pitch;
+    if (mat_pitch > 0) p.mat_pitch = mat_pitch;
+    if (p.obs_pitch < e->view * e->view * 3 || p.mat_pitch < NC) return TW_E_ARG;
+    switch (pick_envs_per_wave(e)) {
+    case 1: launch_variant<1>(e, p, st); break;
+    case 2: launch_variant<2>(e, p, st); break;
+    case 4: launch_variant<4>(e, p, st); break;
+    default: return TW_E_ARG;
+    }
     HIP_TRY(hipGetLastError());
     return TW_OK;
 }
@@ -625,6 +964,8 @@ int tw_create(tw_engine **out, int variant, int n_envs, int view_size, int devic
     if (!e) return TW_E_NOMEM;
     e->variant = variant; e->n_envs = n_envs; e->view = view_size; e->device = device_id;
     e->seed = seed; e->env_id0 = env_id0;
+    const char *epw = getenv("TW_ENVS_PER_WAVE");
+    e->envs_per_wave = epw ? atoi(epw) : 0;
     hipError_t r1 = hipMalloc((void **)&e->type, (size_t)n_envs * NC);
     hipError_t r2 = hipMalloc((void **)&e->colour, (size_t)n_envs * NC);
     hipError_t r3 = hipMalloc((void **)&e->rec, (size_t)n_envs * REC * sizeof(int32_t));
@@ -652,31 +993,40 @@ int tw_destroy(tw_engine *e) {
     return TW_OK;
 }
 
-int tw_reset(tw_engine *e, const uint8_t *mask, uint8_t *obs, void *stream) {
+int tw_set_envs_per_wave(tw_engine *e, int envs_per_wave) {
+    if (!e || !(envs_per_wave == 0 || envs_per_wave == 1 || envs_per_wave == 2 || envs_per_wave == 4)) return TW_E_ARG;
+    e->envs_per_wave = envs_per_wave;
+    return TW_OK;
+}
+
+int tw_reset(tw_engine *e, const uint8_t *mask, uint8_t *obs, int obs_pitch, void *stream) {
     if (!e) return TW_E_ARG;
     DeviceGuard g(e->device);
     Params p = base_params(e);
     p.obs = obs;
+    if (obs_pitch > 0) p.obs_pitch = obs_pitch;
+    if (p.obs_pitch < e->view * e->view * 3) return TW_E_ARG;
     hipLaunchKernelGGL(tw_reset_kernel, dim3(e->n_envs), dim3(64), 0, (hipStream_t)stream, p, mask, 1);
     HIP_TRY(hipGetLastError());
     return TW_OK;
 }
 
-int tw_step(tw_engine *e, const int32_t *actions, const uint32_t *draws, uint8_t *obs, float *state_matrix,
-            float *pos, float *reward, uint8_t *terminated, uint8_t *truncated, int flags, void *stream) {
+int tw_step(tw_engine *e, const int32_t *actions, const uint32_t *draws, uint8_t *obs, int obs_pitch,
+            float *state_matrix, int mat_pitch, float *pos, float *reward, uint8_t *terminated, uint8_t *truncated,
+            int flags, void *stream) {
     if (!e || !actions) return TW_E_ARG;
     DeviceGuard g(e->device);
-    return launch_rollout(e, 1, actions, draws, obs, state_matrix, pos, reward, terminated, truncated, flags,
-                          (hipStream_t)stream);
+    return launch_rollout(e, 1, actions, draws, obs, obs_pitch, state_matrix, mat_pitch, pos, reward, terminated,
+                          truncated, flags, (hipStream_t)stream);
 }
 
-int tw_rollout(tw_engine *e, int T, const int32_t *actions, const uint32_t *draws, uint8_t *obs,
-               float *state_matrix, float *pos, float *reward, uint8_t *terminated, uint8_t *truncated,
-               int flags, void *stream) {
+int tw_rollout(tw_engine *e, int T, const int32_t *actions, const uint32_t *draws, uint8_t *obs, int obs_pitch,
+               float *state_matrix, int mat_pitch, float *pos, float *reward, uint8_t *terminated,
+               uint8_t *truncated, int flags, void *stream) {
     if (!e || T <= 0) return TW_E_ARG;
     DeviceGuard g(e->device);
-    return launch_rollout(e, T, actions, draws, obs, state_matrix, pos, reward, terminated, truncated, flags,
-                          (hipStream_t)stream);
+    return launch_rollout(e, T, actions, draws, obs, obs_pitch, state_matrix, mat_pitch, pos, reward, terminated,
+                          truncated, flags, (hipStream_t)stream);
 }
 
 int tw_fill_actions(tw_engine *e, int T, int32_t *actions, void *stream) {
@@ -720,11 +1070,13 @@ int tw_set_state_host(tw_engine *e, const uint8_t *type_plane, const uint8_t *co
     return TW_OK;
 }
 
-int tw_gen_obs(tw_engine *e, int view_size, uint8_t *obs, void *stream) {
+int tw_gen_obs(tw_engine *e, int view_size, uint8_t *obs, int obs_pitch, void *stream) {
     if (!e || !obs || !view_ok(view_size)) return TW_E_ARG;
     DeviceGuard g(e->device);
     Params p = base_params(e);
     p.view = view_size; p.obs = obs;
+    p.obs_pitch = obs_pitch > 0 ? obs_pitch : view_size * view_size * 3;
+    if (p.obs_pitch < view_size * view_size * 3) return TW_E_ARG;
     hipLaunchKernelGGL(tw_gen_obs_kernel, dim3(e->n_envs), dim3(64), 0, (hipStream_t)stream, p);
     HIP_TRY(hipGetLastError());
     return TW_OK;
@@ -734,11 +1086,11 @@ int tw_n_envs(const tw_engine *e) { return e ? e->n_envs : TW_E_ARG; }
 int tw_view_size(const tw_engine *e) { return e ? e->view : TW_E_ARG; }
 int tw_last_hip_error(void) { return g_last_hip_error; }
 const char *tw_last_error_message(void) { return g_last_error_msg; }
-const char *tw_version(void) { return "twoarmy-hip 0.1 (gfx950)"; }
+const char *tw_version(void) { return "twoarmy-hip 0.2 (gfx950)"; }
 
-int tw_time_rollout(tw_engine *e, int T, const int32_t *actions, uint8_t *obs, float *state_matrix, float *pos,
-                    float *reward, uint8_t *terminated, uint8_t *truncated, int flags, int iters, void *stream,
-                    float *ms_per_launch) {
+int tw_time_rollout(tw_engine *e, int T, const int32_t *actions, uint8_t *obs, int obs_pitch, float *state_matrix,
+                    int mat_pitch, float *pos, float *reward, uint8_t *terminated, uint8_t *truncated, int flags,
+                    int iters, void *stream, float *ms_per_launch) {
     if (!e || T <= 0 || iters <= 0 || !ms_per_launch) return TW_E_ARG;
     DeviceGuard g(e->device);
     hipStream_t st = (hipStream_t)stream;
@@ -747,8 +1099,8 @@ int tw_time_rollout(tw_engine *e, int T, const int32_t *actions, uint8_t *obs, f
     HIP_TRY(hipEventCreate(&b));
     HIP_TRY(hipEventRecord(a, st));
     for (int i = 0; i < iters; ++i) {
-        int rc = launch_rollout(e, T, actions, nullptr, obs, state_matrix, pos, reward, terminated, truncated,
-                                flags, st);
+        int rc = launch_rollout(e, T, actions, nullptr, obs, obs_pitch, state_matrix, mat_pitch, pos, reward,
+                                terminated, truncated, flags, st);
         if (rc != TW_OK) return rc;
     }
     HIP_TRY(hipEventRecord(b, st));

@@ -11,15 +11,53 @@ from . import _lib
 from ._lib import FIELDS, TW_CELLS, TW_DRAW_WORDS, TW_F_AUTORESET, TW_F_POLICY_IDX, TW_REC_WORDS
 
 REWARD_VALUES = (-0.01, -0.1, -0.9, 0.2, 0.9)
+MAT_PITCH = 292                       # floats per env matrix in the native layout (289 + 3 zero pad)
+
+
+def obs_pitch_for(view):
+    """Bytes per env image in the native layout: V*V*3 rounded up to 16 (880 for V=17)."""
+    return (view * view * 3 + 15) // 16 * 16
 
 
 def _ptr(t, dtype=None):
     if t is None:
         return None
-    assert t.is_cuda and t.is_contiguous(), "engine buffers must be contiguous device tensors"
+    assert t.is_cuda, "engine buffers must be device tensors"
     if dtype is not None:
         assert t.dtype == dtype, "expected %s, got %s" % (dtype, t.dtype)
     return C.c_void_p(t.data_ptr())
+
+
+def _dense(t, dtype):
+    assert t is None or (t.is_contiguous() and t.dtype == dtype), "expected contiguous %s" % dtype
+    return _ptr(t)
+
+
+def _pitched(t, lead, inner_shape, dtype):
+    """(pointer, pitch in elements) of a [*lead, *inner_shape] tensor whose rows may be padded."""
+    if t is None:
+        return None, 0
+    assert t.is_cuda and t.dtype == dtype, "expected %s device tensor" % dtype
+    nlead = len(lead)
+    assert tuple(t.shape) == tuple(lead) + tuple(inner_shape), (tuple(t.shape), lead, inner_shape)
+    inner = 1
+    for d in range(t.dim() - 1, nlead - 1, -1):            # inner dims must be dense
+        assert t.stride(d) == inner or t.shape[d] == 1, "inner dims of an engine buffer must be dense"
+        inner *= t.shape[d]
+    # row pitch from the innermost leading dim of size > 1 (strides of size-1 dims are arbitrary)
+    pitch, mult = None, 1
+    for d in range(nlead - 1, -1, -1):
+        if t.shape[d] > 1:
+            if pitch is None:
+                assert t.stride(d) % mult == 0
+                pitch = t.stride(d) // mult
+            else:
+                assert t.stride(d) == pitch * mult, "leading dims must be dense"
+        mult *= t.shape[d]
+    if pitch is None:
+        pitch = inner
+    assert pitch >= inner
+    return C.c_void_p(t.data_ptr()), int(pitch)
 
 
 class TwoarmyEngine:
@@ -58,14 +96,28 @@ class TwoarmyEngine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def set_envs_per_wave(self, e):
+        _lib.check(_lib.lib().tw_set_envs_per_wave(self._h, int(e)), "tw_set_envs_per_wave")
+
     # ------------------------------------------------------------------ buffers
-    def alloc_outputs(self, T=None, obs=True, matrix=True):
+    def alloc_outputs(self, T=None, obs=True, matrix=True, dense=False):
+        """Output tensors for step (T=None -> [N,...]) or rollout ([T,N,...]).
+
+        Native layout (dense=False): obs rows padded to 16 bytes (880 for V=17) and matrix rows to
+        292 floats; the returned tensors are [..., V, V, 3] / [..., 289] strided views of them."""
         N, V = self.num_envs, self.view_size
         lead = (N,) if T is None else (T, N)
         d = self.device
+        nb = V * V * 3
+        if dense:
+            o = torch.empty(lead + (V, V, 3), dtype=torch.uint8, device=d) if obs else None
+            m = torch.empty(lead + (TW_CELLS,), dtype=torch.float32, device=d) if matrix else None
+        else:
+            o = torch.empty(lead + (obs_pitch_for(V),), dtype=torch.uint8, device=d)[..., :nb].view(lead + (V, V, 3)) \
+                if obs else None
+            m = torch.empty(lead + (MAT_PITCH,), dtype=torch.float32, device=d)[..., :TW_CELLS] if matrix else None
         return dict(
-            obs=torch.empty(lead + (V, V, 3), dtype=torch.uint8, device=d) if obs else None,
-            matrix=torch.empty(lead + (TW_CELLS,), dtype=torch.float32, device=d) if matrix else None,
+            obs=o, matrix=m,
             pos=torch.empty(lead + (2,), dtype=torch.float32, device=d),
             reward=torch.empty(lead, dtype=torch.float32, device=d),
             terminated=torch.empty(lead, dtype=torch.uint8, device=d),
@@ -74,37 +126,39 @@ class TwoarmyEngine:
 
     # ------------------------------------------------------------------ ops
     def reset(self, mask=None, obs=None):
-        _lib.check(_lib.lib().tw_reset(self._h, _ptr(mask, torch.uint8), _ptr(obs, torch.uint8), self._stream()),
-                   "tw_reset")
+        V = self.view_size
+        op, opitch = _pitched(obs, (self.num_envs,), (V, V, 3), torch.uint8)
+        _lib.check(_lib.lib().tw_reset(self._h, _dense(mask, torch.uint8), op, opitch, self._stream()), "tw_reset")
         return obs
+
+    def _launch(self, fn, name, lead, T, actions, draws, out, flags):
+        V = self.view_size
+        op, opitch = _pitched(out.get("obs"), lead, (V, V, 3), torch.uint8)
+        mp, mpitch = _pitched(out.get("matrix"), lead, (TW_CELLS,), torch.float32)
+        for k, dt in (("pos", torch.float32), ("reward", torch.float32), ("terminated", torch.uint8),
+                      ("truncated", torch.uint8)):
+            t = out.get(k)
+            assert t is None or (t.is_contiguous() and t.dtype == dt and tuple(t.shape[:len(lead)]) == lead), k
+        args = [self._h] + ([T] if T is not None else []) + [
+            _dense(actions, torch.int32), _ptr(draws), op, opitch, mp, mpitch, _ptr(out.get("pos")),
+            _ptr(out.get("reward")), _ptr(out.get("terminated")), _ptr(out.get("truncated")), flags, self._stream()]
+        _lib.check(fn(*args), name)
+        return out
 
     def step(self, actions, out, draws=None, autoreset=False, policy_idx=False):
         flags = (TW_F_AUTORESET if autoreset else 0) | (TW_F_POLICY_IDX if policy_idx else 0)
         assert actions.shape == (self.num_envs,)
         if draws is not None:
-            assert draws.shape == (self.num_envs, TW_DRAW_WORDS) and draws.dtype == torch.int32
-        _lib.check(_lib.lib().tw_step(
-            self._h, _ptr(actions, torch.int32), _ptr(draws), _ptr(out.get("obs"), torch.uint8),
-            _ptr(out.get("matrix"), torch.float32), _ptr(out.get("pos"), torch.float32),
-            _ptr(out.get("reward"), torch.float32), _ptr(out.get("terminated"), torch.uint8),
-            _ptr(out.get("truncated"), torch.uint8), flags, self._stream()), "tw_step")
-        return out
+            assert draws.shape == (self.num_envs, TW_DRAW_WORDS) and draws.dtype == torch.int32 and draws.is_contiguous()
+        return self._launch(_lib.lib().tw_step, "tw_step", (self.num_envs,), None, actions, draws, out, flags)
 
     def rollout(self, T, out, actions=None, draws=None, autoreset=True, policy_idx=True):
         flags = (TW_F_AUTORESET if autoreset else 0) | (TW_F_POLICY_IDX if policy_idx else 0)
         if actions is not None:
             assert actions.shape == (T, self.num_envs)
         if draws is not None:
-            assert draws.shape == (T, self.num_envs, TW_DRAW_WORDS) and draws.dtype == torch.int32
-        for k in ("obs", "matrix", "pos", "reward", "terminated", "truncated"):
-            t = out.get(k)
-            assert t is None or t.shape[:2] == (T, self.num_envs), k
-        _lib.check(_lib.lib().tw_rollout(
-            self._h, T, _ptr(actions, torch.int32), _ptr(draws), _ptr(out.get("obs"), torch.uint8),
-            _ptr(out.get("matrix"), torch.float32), _ptr(out.get("pos"), torch.float32),
-            _ptr(out.get("reward"), torch.float32), _ptr(out.get("terminated"), torch.uint8),
-            _ptr(out.get("truncated"), torch.uint8), flags, self._stream()), "tw_rollout")
-        return out
+            assert draws.shape == (T, self.num_envs, TW_DRAW_WORDS) and draws.dtype == torch.int32 and draws.is_contiguous()
+        return self._launch(_lib.lib().tw_rollout, "tw_rollout", (T, self.num_envs), T, actions, draws, out, flags)
 
     def fill_actions(self, T):
         a = torch.empty((T, self.num_envs), dtype=torch.int32, device=self.device)
@@ -114,15 +168,19 @@ class TwoarmyEngine:
     def gen_obs(self, view_size=None):
         V = view_size or self.view_size
         obs = torch.empty((self.num_envs, V, V, 3), dtype=torch.uint8, device=self.device)
-        _lib.check(_lib.lib().tw_gen_obs(self._h, V, _ptr(obs), self._stream()), "tw_gen_obs")
+        _lib.check(_lib.lib().tw_gen_obs(self._h, V, _ptr(obs), 0, self._stream()), "tw_gen_obs")
         return obs
 
     def time_rollout(self, T, out, actions=None, autoreset=True, iters=10):
         """Mean kernel time (ms) of one tw_rollout launch, HIP events on the current stream."""
         ms = C.c_float()
+        V = self.view_size
+        lead = (T, self.num_envs)
         flags = (TW_F_AUTORESET if autoreset else 0) | TW_F_POLICY_IDX
+        op, opitch = _pitched(out.get("obs"), lead, (V, V, 3), torch.uint8)
+        mp, mpitch = _pitched(out.get("matrix"), lead, (TW_CELLS,), torch.float32)
         _lib.check(_lib.lib().tw_time_rollout(
-            self._h, T, _ptr(actions, torch.int32), _ptr(out.get("obs")), _ptr(out.get("matrix")),
+            self._h, T, _dense(actions, torch.int32), op, opitch, mp, mpitch,
             _ptr(out.get("pos")), _ptr(out.get("reward")), _ptr(out.get("terminated")), _ptr(out.get("truncated")),
             flags, iters, self._stream(), C.byref(ms)), "tw_time_rollout")
         return ms.value
@@ -139,6 +197,8 @@ class TwoarmyEngine:
         return ty, co, rec
 
     def set_state(self, type_plane=None, colour_plane=None, records=None):
+        keep = []
+
         def p(a, dt, shape):
             if a is None:
                 return None
@@ -146,15 +206,10 @@ class TwoarmyEngine:
             assert a.shape == shape
             keep.append(a)
             return a.ctypes.data_as(C.c_void_p)
-        keep = []
         N = self.num_envs
         _lib.check(_lib.lib().tw_set_state_host(self._h, p(type_plane, np.uint8, (N, TW_CELLS)),
                                                 p(colour_plane, np.uint8, (N, TW_CELLS)),
                                                 p(records, np.int32, (N, TW_REC_WORDS))), "tw_set_state_host")
-
-    def state_tensors(self):
-        """Zero-copy device views of the engine's SoA state (type, colour, records)."""
-        raise NotImplementedError("use get_state()/set_state(); device views arrive with the DLPack bridge")
 
     @staticmethod
     def field(records, name, k=0):

@@ -79,7 +79,7 @@ int tw_destroy(tw_engine *e);
 /* MiniGridEnv.reset (minigrid.py:947-980): regenerate the grid, step_count = 0; Twoarmy flags are
  * NOT touched (twoarmy_v6.py has no reset override).  mask: uint8[n_envs] or NULL (= all).
  * obs (nullable): uint8[n_envs][V][V][3] first observation (only rows with mask set are written). */
-int tw_reset(tw_engine *e, const uint8_t *mask, uint8_t *obs, void *stream);
+int tw_reset(tw_engine *e, const uint8_t *mask, uint8_t *obs, int obs_pitch, void *stream);
 
 /* One Twoarmy_v{4,6}.step for every env (twoarmy_v6.py:83-325 / twoarmy_v4.py:82-322, incl.
  * MiniGridEnv.step minigrid.py:1333-1441, gen_obs :1443-1496) fused with
@@ -91,17 +91,25 @@ int tw_reset(tw_engine *e, const uint8_t *mask, uint8_t *obs, void *stream);
  *   pos            float[N][2]         agent (y, x)
  *   reward         float[N]            {-0.01,-0.1,-0.9,0.2,0.9}
  *   terminated, truncated  uint8[N]
+ * Pitches (MI355X layout): obs_pitch = bytes between consecutive envs' images (0 = dense V*V*3),
+ * mat_pitch = floats between consecutive envs' matrices (0 = dense 289).  With a 16-byte aligned
+ * base, obs_pitch % 16 == 0 and >= roundup(V*V*3, 16) (880 for V=17), mat_pitch % 4 == 0 and >= 292
+ * the engine takes its register-packed dwordx4 path and also writes the pad bytes/floats (zeros);
+ * any other layout (incl. dense) uses a slower, equally exact generic path.
  */
-int tw_step(tw_engine *e, const int32_t *actions, const uint32_t *draws, uint8_t *obs,
-            float *state_matrix, float *pos, float *reward, uint8_t *terminated, uint8_t *truncated,
-            int flags, void *stream);
+int tw_step(tw_engine *e, const int32_t *actions, const uint32_t *draws, uint8_t *obs, int obs_pitch,
+            float *state_matrix, int mat_pitch, float *pos, float *reward, uint8_t *terminated,
+            uint8_t *truncated, int flags, void *stream);
 
 /* T consecutive steps in ONE launch (the rollout of soa/train_ppo.py:107-123 with a supplied
  * action stream).  All arrays are time-major [T][N][...].  actions NULL -> policy indices from the
  * Philox action slot (implies TW_F_POLICY_IDX).  Grid planes stay in LDS for the whole launch. */
 int tw_rollout(tw_engine *e, int T, const int32_t *actions, const uint32_t *draws, uint8_t *obs,
-               float *state_matrix, float *pos, float *reward, uint8_t *terminated,
-               uint8_t *truncated, int flags, void *stream);
+               int obs_pitch, float *state_matrix, int mat_pitch, float *pos, float *reward,
+               uint8_t *terminated, uint8_t *truncated, int flags, void *stream);
+
+/* Envs per wavefront of the rollout kernel: 1, 2 or 4 (0 = auto from n_envs; also TW_ENVS_PER_WAVE). */
+int tw_set_envs_per_wave(tw_engine *e, int envs_per_wave);
 
 /* Fill int32[T][N] with the Philox action-slot policy indices the engine would use for its next
  * T steps (t counted from each env's current TW_T). */
@@ -116,7 +124,7 @@ int tw_set_state_host(tw_engine *e, const uint8_t *type_plane, const uint8_t *co
                       const int32_t *records);
 
 /* gen_obs_grid(view).encode() for the current state without stepping (minigrid.py:1443-1496). */
-int tw_gen_obs(tw_engine *e, int view_size, uint8_t *obs, void *stream);
+int tw_gen_obs(tw_engine *e, int view_size, uint8_t *obs, int obs_pitch, void *stream);
 
 int tw_n_envs(const tw_engine *e);
 int tw_view_size(const tw_engine *e);
@@ -126,8 +134,9 @@ const char *tw_version(void);
 
 /* Time one launch of the engine kernel with hipEvents on `stream` (bench.py roofline leg):
  * runs tw_rollout `iters` times back-to-back and returns the mean kernel time in milliseconds. */
-int tw_time_rollout(tw_engine *e, int T, const int32_t *actions, uint8_t *obs, float *state_matrix,
-                    float *pos, float *reward, uint8_t *terminated, uint8_t *truncated, int flags,
+int tw_time_rollout(tw_engine *e, int T, const int32_t *actions, uint8_t *obs, int obs_pitch,
+                    float *state_matrix, int mat_pitch, float *pos, float *reward, uint8_t *terminated,
+                    uint8_t *truncated, int flags,
                     int iters, void *stream, float *ms_per_launch);
 
 #ifdef __cplusplus

@@ -105,10 +105,22 @@ def test_views_vs_reference_golden(golden_dir):
     eng.close()
 
 
-def _compare_rollout(variant, N, T, view, env0=0, chunk=None):
+_REF_CACHE = {}
+
+
+def _oracle(variant, N, T, view, env0):
+    key = (variant, N, T, view, env0)
+    if key not in _REF_CACHE:
+        _REF_CACHE.clear()
+        _REF_CACHE[key] = orc.rollout(variant, N, T, SEED, env0=env0, view=view)
+    return _REF_CACHE[key]
+
+
+def _compare_rollout(variant, N, T, view, env0=0, chunk=None, dense=False, epw=0):
     eng = _engine(variant, N, view, seed=SEED, env_id0=env0)
-    ref = orc.rollout(variant, N, T, SEED, env0=env0, view=view)
-    out = eng.alloc_outputs(T)
+    eng.set_envs_per_wave(epw)
+    ref = _oracle(variant, N, T, view, env0)
+    out = eng.alloc_outputs(T, dense=dense)
     if chunk is None:
         eng.rollout(T, out)
     else:                                  # same thing in several launches: state must carry over exactly
@@ -128,23 +140,41 @@ def _compare_rollout(variant, N, T, view, env0=0, chunk=None):
 
 
 @pytest.mark.parametrize("variant", [6, 4])
-def test_rollout_4096_vs_oracle(variant):
-    """BASELINE config 2: 4096 envs, fused T-step launch, bit-exact obs/matrix/reward/done vs the CPU oracle."""
-    ref = _compare_rollout(variant, 4096, 200, 17)
+@pytest.mark.parametrize("dense,epw", [(False, 0), (False, 1), (False, 4), (True, 0), (True, 1)])
+def test_rollout_4096_vs_oracle(variant, dense, epw):
+    """BASELINE config 2: 4096 envs, fused T-step launch, bit-exact obs/matrix/reward/done vs the CPU oracle.
+    Native (16-byte pitched, register-packed path) and dense (generic path) layouts; 1/2/4 envs per wave."""
+    ref = _compare_rollout(variant, 4096, 200, 17, dense=dense, epw=epw)
     assert ref["truncated"].sum() > 0
 
 
+def test_native_layout_pad_is_zero():
+    eng = _engine(4, 130, 17, seed=SEED)
+    out = eng.alloc_outputs(40)
+    out["obs"]._base.fill_(0xAB) if out["obs"]._base is not None else None
+    eng.rollout(40, out)
+    torch.cuda.synchronize()
+    raw_o = out["obs"]._base if out["obs"]._base is not None else out["obs"]
+    raw_m = out["matrix"]._base if out["matrix"]._base is not None else out["matrix"]
+    assert raw_o.shape[-1] == 880 and raw_m.shape[-1] == 292
+    assert int(raw_o[..., 867:].max()) == 0
+    assert float(raw_m[..., 289:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("variant,view,N,T,env0", [(6, 7, 513, 130, 0), (4, 7, 257, 150, 12345), (4, 3, 65, 64, 7),
-                                                   (6, 5, 1, 120, 4095), (4, 17, 1000, 100, 1 << 20)])
-def test_rollout_shapes_vs_oracle(variant, view, N, T, env0):
-    """ragged N (not a multiple of 4/64), small views, sharded env-id offsets"""
-    _compare_rollout(variant, N, T, view, env0=env0)
+                                                   (6, 5, 1, 120, 4095), (4, 17, 1000, 100, 1 << 20),
+                                                   (4, 15, 333, 70, 5), (6, 9, 4099, 66, 0)])
+@pytest.mark.parametrize("dense,epw", [(False, 0), (True, 2), (False, 4)])
+def test_rollout_shapes_vs_oracle(variant, view, N, T, env0, dense, epw):
+    """ragged N (not a multiple of 2/4/64), small views, sharded env-id offsets, both layouts"""
+    _compare_rollout(variant, N, T, view, env0=env0, dense=dense, epw=epw)
 
 
 @pytest.mark.parametrize("variant", [6, 4])
 def test_rollout_chunked_equals_single(variant):
     _compare_rollout(variant, 300, 96, 17, chunk=1)      # tw_rollout(T=1) x 96 == oracle
     _compare_rollout(variant, 300, 100, 17, chunk=33)
+    _compare_rollout(variant, 301, 100, 17, chunk=33, dense=True, epw=4)
 
 
 def test_step_api_equals_rollout():
