@@ -1,0 +1,353 @@
+// ppo_kernels.hip -- PPO math kernels for MI355X (gfx950), C ABI in include/twoarmy_ppo.h.
+//
+// Everything here is HBM-bound elementwise / scan work on [T][N] rollout tensors; the conv/linear
+// GEMMs of the actor-critic stay in PyTorch-ROCm (MIOpen / hipBLASLt on MFMA).  Reference arithmetic:
+// soa/agent/PPO.py:73-92 (select_action), :112-115 (targets / advantages), :124-133 (losses).
+
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <stdint.h>
+
+#include "twoarmy.h"
+#include "twoarmy_ppo.h"
+
+namespace {
+
+constexpr float CAT_EPS = FLT_EPSILON;          // torch.finfo(float32).eps used by probs_to_logits
+
+__device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t &c0, uint32_t &c1, uint32_t &c2,
+                                              uint32_t &c3) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t lo0 = 0xD2511F53u * c0, hi0 = __umulhi(0xD2511F53u, c0);
+        const uint32_t lo1 = 0xCD9E8D57u * c2, hi1 = __umulhi(0xCD9E8D57u, c2);
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+// ------------------------------------------------------------------ categorical sample
+template <int A>
+__global__ void ppo_sample_kernel(const float *__restrict__ probs, int B, const float *__restrict__ uniforms,
+                                  uint32_t k0, uint32_t k1, uint64_t offset, int32_t *__restrict__ action,
+                                  float *__restrict__ logp) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float p[A];
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < A; ++k) { p[k] = probs[(size_t)b * A + k]; sum += p[k]; }
+    float u;
+    if (uniforms) u = uniforms[b];
+    else {
+        const uint64_t ctr = (uint64_t)b + offset;
+        uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0, c3 = 0x54574F53u;   // 'TWOS'
+        philox4x32_10(k0, k1, c0, c1, c2, c3);
+        u = (float)(c0 >> 8) * (1.0f / 16777216.0f);       // 24 random bits -> [0, 1)
+    }
+    int a = A - 1;
+    float cum = 0.f, qa = 0.f;
+    bool found = false;
+#pragma unroll
+    for (int k = 0; k < A; ++k) {
+        const float q = p[k] / sum;
+        cum += q;
+        if (!found && cum > u) { a = k; found = true; }
+    }
+#pragma unroll
+    for (int k = 0; k < A; ++k) if (k == a) qa = p[k] / sum;
+    action[b] = a;
+    logp[b] = logf(fminf(fmaxf(qa, CAT_EPS), 1.0f - CAT_EPS));
+}
+
+// ------------------------------------------------------------------ GAE: segmented reverse scan
+// Block = 256 threads = 4 waves, 64 envs (columns) x chunks of 64 time steps walked from T backwards.
+// Lanes of a wave are TIME within one env column: A_t = d_t + c_t * A_{t+1} is the suffix composition
+// of affine maps (c, d), computed with a 6-step Kogge-Stone over __shfl_down; the running A of the
+// chunk above enters as the carry.  Tiles go through LDS so that global accesses stay coalesced.
+constexpr int GT = 64;     // time steps per chunk
+constexpr int GN = 64;     // envs per block
+
+__global__ __launch_bounds__(256) void ppo_gae_kernel(const float *__restrict__ reward, const float *__restrict__ value,
+                                                      const float *__restrict__ next_value,
+                                                      const uint8_t *__restrict__ done, float gamma, float lambda,
+                                                      int use_done_mask, int T, int N, float *__restrict__ adv,
+                                                      float *__restrict__ target, float *__restrict__ ret) {
+    __shared__ float sd[GT][GN + 1];
+    __shared__ float sc[GT][GN + 1];
+    __shared__ float carry[GN];
+    const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+    const int n = blockIdx.x * GN + tx;
+    if (tid < GN) carry[tid] = 0.f;
+    const int nchunks = (T + GT - 1) / GT;
+    for (int ch = nchunks - 1; ch >= 0; --ch) {
+        const int t0 = ch * GT;
+        __syncthreads();
+        for (int r = ty; r < GT; r += 4) {
+            const int t = t0 + r;
+            float d = 0.f, c = 1.f;                     // identity map for rows past T
+            if (t < T && n < N) {
+                const size_t i = (size_t)t * N + n;
+                const float cut = (use_done_mask && done[i]) ? 0.f : 1.f;
+                // same rounding sequence as torch: g*V, * cut, + r, - V   (no fma contraction)
+                const float tv = __fadd_rn(reward[i], __fmul_rn(__fmul_rn(gamma, next_value[i]), cut));
+                if (target) target[i] = tv;
+                d = __fsub_rn(tv, value[i]);
+                c = gamma * lambda * cut;
+            }
+            sd[r][tx] = d; sc[r][tx] = c;
+        }
+        __syncthreads();
+        const int wave = ty, lane = tx;                 // lane = time row inside the chunk
+        for (int e = wave * 16; e < wave * 16 + 16; ++e) {
+            float d = sd[lane][e], c = sc[lane][e];
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const float d2 = __shfl_down(d, off), c2 = __shfl_down(c, off);
+                if (lane + off < 64) { d = fmaf(c, d2, d); c = c * c2; }
+            }
+            const float a = fmaf(c, carry[e], d);       // A of this row given the chunk above
+            sd[lane][e] = a;
+            const float a0 = __shfl(a, 0);
+            if (lane == 0) carry[e] = a0;               // only this wave touches carry[e]
+        }
+        __syncthreads();
+        for (int r = ty; r < GT; r += 4) {
+            const int t = t0 + r;
+            if (t < T && n < N) {
+                const size_t i = (size_t)t * N + n;
+                const float a = sd[r][tx];
+                if (adv) adv[i] = a;
+                if (ret) ret[i] = a + value[i];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ advantage normalisation
+__global__ __launch_bounds__(256) void ppo_moments_kernel(const float *__restrict__ x, int64_t n, double *__restrict__ ws) {
+    __shared__ double s1[256], s2[256];
+    double a = 0.0, b = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double v = (double)x[i];
+        a += v; b += v * v;
+    }
+    s1[threadIdx.x] = a; s2[threadIdx.x] = b;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { s1[threadIdx.x] += s1[threadIdx.x + s]; s2[threadIdx.x] += s2[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { ws[2 * blockIdx.x] = s1[0]; ws[2 * blockIdx.x + 1] = s2[0]; }
+}
+
+__global__ __launch_bounds__(256) void ppo_normalise_kernel(float *__restrict__ x, int64_t n, float eps,
+                                                            const double *__restrict__ ws, int nblocks) {
+    __shared__ float s_mean, s_inv;
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < nblocks; ++k) { a += ws[2 * k]; b += ws[2 * k + 1]; }   // fixed order
+        const double mean = a / (double)n;
+        double var = n > 1 ? (b - (double)n * mean * mean) / (double)(n - 1) : 0.0;  // unbiased
+        if (var < 0.0) var = 0.0;
+        s_mean = (float)mean;
+        s_inv = 1.0f / ((float)sqrt(var) + eps);
+    }
+    __syncthreads();
+    const float mean = s_mean, inv = s_inv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        x[i] = (x[i] - mean) * inv;
+}
+
+// ------------------------------------------------------------------ fused PPO losses, forward + backward
+template <int A>
+__global__ __launch_bounds__(256) void ppo_loss_kernel(const float *__restrict__ probs, const int32_t *__restrict__ action,
+                                                       const float *__restrict__ old_logp, const float *__restrict__ adv,
+                                                       const float *__restrict__ value, const float *__restrict__ target_v,
+                                                       int B, float clip, float ent_coef, float *__restrict__ grad_probs,
+                                                       float *__restrict__ grad_value, float *__restrict__ ws) {
+    __shared__ float sa[256], sv[256];
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    float la = 0.f, lv = 0.f;
+    if (b < B) {
+        const float invB = 1.0f / (float)B;
+        float p[A], q[A], l[A];
+        bool inside[A];
+        float S = 0.f;
+#pragma unroll
+        for (int k = 0; k < A; ++k) { p[k] = probs[(size_t)b * A + k]; S += p[k]; }
+        float H = 0.f;
+#pragma unroll
+        for (int k = 0; k < A; ++k) {
+            q[k] = p[k] / S;
+            inside[k] = q[k] >= CAT_EPS && q[k] <= 1.0f - CAT_EPS;        // clamp passes gradient inside (inclusive)
+            l[k] = logf(fminf(fmaxf(q[k], CAT_EPS), 1.0f - CAT_EPS));
+            H -= q[k] * l[k];
+        }
+        const int a = action[b];
+        float la_logp = 0.f;
+#pragma unroll
+        for (int k = 0; k < A; ++k) if (k == a) la_logp = l[k];
+        const float ratio = expf(la_logp - old_logp[b]);
+        const float ad = adv[b];
+        const float lo = 1.0f - clip, hi = 1.0f + clip;
+        const float s1 = ratio * ad;
+        const float s2 = fminf(fmaxf(ratio, lo), hi) * ad;
+        la = -fminf(s1, s2) - ent_coef * H;
+        // d/d(ratio) of min(s1, s2): torch.minimum splits ties; clamp passes gradient on [lo, hi]
+        const bool in_clip = ratio >= lo && ratio <= hi;
+        float w1 = s1 < s2 ? 1.f : (s1 == s2 ? 0.5f : 0.f);
+        float w2 = s2 < s1 ? 1.f : (s1 == s2 ? 0.5f : 0.f);
+        const float g_ratio = -(w1 + (in_clip ? w2 : 0.f)) * ad;
+        const float g_logp = g_ratio * ratio;
+        // gradient w.r.t. normalised q, then through q = p / S
+        float gq[A];
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < A; ++k) {
+            float g = (k == a && inside[k]) ? g_logp / q[k] : 0.f;
+            g += ent_coef * (l[k] + (inside[k] ? 1.f : 0.f));            // -ent_coef * dH/dq_k
+            gq[k] = g;
+            dot += g * q[k];
+        }
+#pragma unroll
+        for (int k = 0; k < A; ++k) grad_probs[(size_t)b * A + k] = (gq[k] - dot) / S * invB;
+        // SmoothL1 (beta = 1)
+        const float d = value[b] - target_v[b];
+        const float ab = fabsf(d);
+        lv = ab < 1.0f ? 0.5f * d * d : ab - 0.5f;
+        grad_value[b] = (ab < 1.0f ? d : (d > 0.f ? 1.f : -1.f)) * invB;
+    }
+    sa[threadIdx.x] = la; sv[threadIdx.x] = lv;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { sa[threadIdx.x] += sa[threadIdx.x + s]; sv[threadIdx.x] += sv[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { ws[2 * blockIdx.x] = sa[0]; ws[2 * blockIdx.x + 1] = sv[0]; }
+}
+
+__global__ void ppo_loss_finalize_kernel(const float *__restrict__ ws, int nblocks, int B, float *__restrict__ losses) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float a = 0.f, v = 0.f;
+        for (int k = 0; k < nblocks; ++k) { a += ws[2 * k]; v += ws[2 * k + 1]; }       // fixed order
+        losses[0] = a / (float)B;
+        losses[1] = v / (float)B;
+    }
+}
+
+// ------------------------------------------------------------------ stack gather / age scan
+__global__ __launch_bounds__(64) void ppo_gather_stack_kernel(const float *__restrict__ frames, int frame_pitch,
+                                                              const float *__restrict__ pos_frames, int N,
+                                                              const int32_t *__restrict__ k_idx,
+                                                              const int32_t *__restrict__ n_idx,
+                                                              const int32_t *__restrict__ age,
+                                                              const float *__restrict__ init_frame,
+                                                              const float *__restrict__ init_pos, int B,
+                                                              float *__restrict__ out, float *__restrict__ pos_out) {
+    const int b = blockIdx.x >> 2, j = blockIdx.x & 3;     // one wave per (sample, stack slot)
+    if (b >= B) return;
+    const int lane = threadIdx.x;
+    const int back = 3 - j;
+    const bool use_init = age[b] - back <= 0;
+    const size_t row = ((size_t)(k_idx[b] - back) * N + n_idx[b]);
+    const float *src = use_init ? init_frame : frames + row * frame_pitch;
+    float *dst = out + ((size_t)b * 4 + j) * TW_CELLS;
+    for (int c = lane; c < TW_CELLS; c += 64) dst[c] = src[c];
+    if (pos_out && lane < 2) {
+        const float *ps = use_init ? init_pos : pos_frames + row * 2;
+        pos_out[((size_t)b * 4 + j) * 2 + lane] = ps[lane];
+    }
+}
+
+__global__ void ppo_age_scan_kernel(const uint8_t *__restrict__ terminated, const uint8_t *__restrict__ truncated,
+                                    const int32_t *__restrict__ age0, int T, int N, int32_t *__restrict__ age) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    int a = age0[n];
+    age[n] = a;
+    for (int t = 0; t < T; ++t) {
+        const size_t i = (size_t)t * N + n;
+        a = (terminated[i] | truncated[i]) ? 0 : a + 1;
+        age[(size_t)(t + 1) * N + n] = a;
+    }
+}
+
+int check_launch() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? TW_OK : TW_E_HIP;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ppo_sample(const float *probs, int B, int A, const float *uniforms, uint64_t seed, uint64_t offset,
+               int32_t *action, float *logp, void *stream) {
+    if (!probs || !action || !logp || B <= 0) return TW_E_ARG;
+    const dim3 grid((B + 255) / 256), block(256);
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    hipStream_t st = (hipStream_t)stream;
+    switch (A) {
+    case 5: hipLaunchKernelGGL(ppo_sample_kernel<5>, grid, block, 0, st, probs, B, uniforms, k0, k1, offset, action, logp); break;
+    case 2: hipLaunchKernelGGL(ppo_sample_kernel<2>, grid, block, 0, st, probs, B, uniforms, k0, k1, offset, action, logp); break;
+    case 3: hipLaunchKernelGGL(ppo_sample_kernel<3>, grid, block, 0, st, probs, B, uniforms, k0, k1, offset, action, logp); break;
+    case 4: hipLaunchKernelGGL(ppo_sample_kernel<4>, grid, block, 0, st, probs, B, uniforms, k0, k1, offset, action, logp); break;
+    case 7: hipLaunchKernelGGL(ppo_sample_kernel<7>, grid, block, 0, st, probs, B, uniforms, k0, k1, offset, action, logp); break;
+    default: return TW_E_ARG;
+    }
+    return check_launch();
+}
+
+int ppo_gae(const float *reward, const float *value, const float *next_value, const uint8_t *done, float gamma,
+            float lambda, int use_done_mask, int T, int N, float *adv, float *target, float *ret, void *stream) {
+    if (!reward || !value || !next_value || T <= 0 || N <= 0 || (use_done_mask && !done)) return TW_E_ARG;
+    hipLaunchKernelGGL(ppo_gae_kernel, dim3((N + GN - 1) / GN), dim3(256), 0, (hipStream_t)stream, reward, value,
+                       next_value, done, gamma, lambda, use_done_mask, T, N, adv, target, ret);
+    return check_launch();
+}
+
+int ppo_adv_norm(float *adv, int64_t n, float eps, double *workspace, void *stream) {
+    if (!adv || n <= 0 || !workspace) return TW_E_ARG;
+    int nblocks = (int)((n + 255) / 256);
+    if (nblocks > 2048) nblocks = 2048;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(ppo_moments_kernel, dim3(nblocks), dim3(256), 0, st, adv, n, workspace);
+    hipLaunchKernelGGL(ppo_normalise_kernel, dim3(nblocks), dim3(256), 0, st, adv, n, eps, workspace, nblocks);
+    return check_launch();
+}
+
+int ppo_loss_fwd_bwd(const float *probs, const int32_t *action, const float *old_logp, const float *adv,
+                     const float *value, const float *target_v, int B, int A, float clip, float ent_coef,
+                     float *losses, float *grad_probs, float *grad_value, float *workspace, void *stream) {
+    if (!probs || !action || !old_logp || !adv || !value || !target_v || !losses || !grad_probs || !grad_value ||
+        !workspace || B <= 0 || A != 5)
+        return TW_E_ARG;
+    const int nblocks = (B + 255) / 256;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(ppo_loss_kernel<5>, dim3(nblocks), dim3(256), 0, st, probs, action, old_logp, adv, value,
+                       target_v, B, clip, ent_coef, grad_probs, grad_value, workspace);
+    hipLaunchKernelGGL(ppo_loss_finalize_kernel, dim3(1), dim3(64), 0, st, workspace, nblocks, B, losses);
+    return check_launch();
+}
+
+int ppo_gather_stack(const float *frames, int frame_pitch, const float *pos_frames, int N, const int32_t *k_idx,
+                     const int32_t *n_idx, const int32_t *age, const float *init_frame, const float *init_pos, int B,
+                     float *out, float *pos_out, void *stream) {
+    if (!frames || !k_idx || !n_idx || !age || !init_frame || !out || B <= 0 || frame_pitch < TW_CELLS) return TW_E_ARG;
+    if (pos_out && (!pos_frames || !init_pos)) return TW_E_ARG;
+    hipLaunchKernelGGL(ppo_gather_stack_kernel, dim3(B * 4), dim3(64), 0, (hipStream_t)stream, frames, frame_pitch,
+                       pos_frames, N, k_idx, n_idx, age, init_frame, init_pos, B, out, pos_out);
+    return check_launch();
+}
+
+int ppo_age_scan(const uint8_t *terminated, const uint8_t *truncated, const int32_t *age0, int T, int N, int32_t *age,
+                 void *stream) {
+    if (!terminated || !truncated || !age0 || !age || T <= 0 || N <= 0) return TW_E_ARG;
+    hipLaunchKernelGGL(ppo_age_scan_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, terminated,
+                       truncated, age0, T, N, age);
+    return check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,105 @@
+"""torch front end of the PPO HIP kernels (include/twoarmy_ppo.h).  No CPU fallback: every op
+needs device tensors and the HIP library."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _p(t, dtype=None):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "PPO kernels take contiguous device tensors"
+    if dtype is not None:
+        assert t.dtype == dtype, "expected %s got %s" % (dtype, t.dtype)
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream(t):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def sample(probs, uniforms=None, seed=0, offset=0):
+    """Categorical(probs).sample() + log_prob (reference soa/agent/PPO.py:86-88) -> (int32[B], float[B])."""
+    B, A = probs.shape
+    action = torch.empty(B, dtype=torch.int32, device=probs.device)
+    logp = torch.empty(B, dtype=torch.float32, device=probs.device)
+    _lib.check(_lib.lib().ppo_sample(_p(probs, torch.float32), B, A, _p(uniforms, torch.float32), seed, offset,
+                                     _p(action), _p(logp), _stream(probs)), "ppo_sample")
+    return action, logp
+
+
+def gae(reward, value, next_value, done=None, gamma=0.99, lam=0.0, use_done_mask=False, want_ret=True):
+    """Returns (adv, target, ret) [T,N].  lam=0, use_done_mask=False is the reference (PPO.py:113-114)."""
+    T, N = reward.shape
+    adv = torch.empty_like(reward)
+    target = torch.empty_like(reward)
+    ret = torch.empty_like(reward) if want_ret else None
+    _lib.check(_lib.lib().ppo_gae(_p(reward, torch.float32), _p(value, torch.float32), _p(next_value, torch.float32),
+                                  _p(done, torch.uint8), gamma, lam, int(bool(use_done_mask)), T, N, _p(adv), _p(target),
+                                  _p(ret), _stream(reward)), "ppo_gae")
+    return adv, target, ret
+
+
+def adv_norm_(adv, eps=1e-8):
+    ws = torch.empty(4096, dtype=torch.float64, device=adv.device)
+    _lib.check(_lib.lib().ppo_adv_norm(_p(adv, torch.float32), adv.numel(), eps, _p(ws), _stream(adv)), "ppo_adv_norm")
+    return adv
+
+
+class _AttachGrad(torch.autograd.Function):
+    """Scalar loss whose gradient w.r.t. `x` was already produced by the fused HIP kernel."""
+
+    @staticmethod
+    def forward(ctx, x, loss, grad):
+        ctx.save_for_backward(grad)
+        ctx.xshape = x.shape
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return (grad * g).view(ctx.xshape), None, None
+
+
+def ppo_losses(probs, value, action, old_logp, adv, target_v, clip=0.1, ent_coef=0.01):
+    """(action_loss, value_loss) of the reference (PPO.py:124-133).  One fused forward+backward launch;
+    the two losses are separate autograd nodes so `action_loss.backward(); value_loss.backward()` works
+    exactly like in the reference."""
+    B, A = probs.shape
+    with torch.no_grad():
+        probs_c = probs.detach().contiguous()
+        value_c = value.detach().contiguous().view(-1)
+        losses = torch.empty(2, dtype=torch.float32, device=probs.device)
+        gp = torch.empty_like(probs_c)
+        gv = torch.empty_like(value_c)
+        ws = torch.empty(2 * ((B + 255) // 256), dtype=torch.float32, device=probs.device)
+        _lib.check(_lib.lib().ppo_loss_fwd_bwd(
+            _p(probs_c, torch.float32), _p(action.contiguous(), torch.int32), _p(old_logp.contiguous().view(-1)),
+            _p(adv.contiguous().view(-1)), _p(value_c), _p(target_v.contiguous().view(-1)), B, A, float(clip),
+            float(ent_coef), _p(losses), _p(gp), _p(gv), _p(ws), _stream(probs)), "ppo_loss_fwd_bwd")
+    return _AttachGrad.apply(probs, losses[0], gp), _AttachGrad.apply(value, losses[1], gv)
+
+
+def gather_stack(frames, pos_frames, k_idx, n_idx, age, init_frame, init_pos):
+    """frames [K,N,pitch>=289] (may be a [..., :289] view of a 292-pitched buffer) -> ([B,4,289], [B,4,2])."""
+    K, N = frames.shape[:2]
+    pitch = frames.stride(1)
+    assert frames.stride(2) == 1 and frames.stride(0) == N * pitch
+    B = k_idx.numel()
+    out = torch.empty((B, 4, 289), dtype=torch.float32, device=frames.device)
+    pos_out = torch.empty((B, 4, 2), dtype=torch.float32, device=frames.device) if pos_frames is not None else None
+    _lib.check(_lib.lib().ppo_gather_stack(
+        C.c_void_p(frames.data_ptr()), pitch, _p(pos_frames, torch.float32), N, _p(k_idx, torch.int32),
+        _p(n_idx, torch.int32), _p(age, torch.int32), _p(init_frame, torch.float32), _p(init_pos, torch.float32), B,
+        _p(out), _p(pos_out), _stream(frames)), "ppo_gather_stack")
+    return out, pos_out
+
+
+def age_scan(terminated, truncated, age0):
+    T, N = terminated.shape
+    age = torch.empty((T + 1, N), dtype=torch.int32, device=terminated.device)
+    _lib.check(_lib.lib().ppo_age_scan(_p(terminated, torch.uint8), _p(truncated, torch.uint8), _p(age0, torch.int32),
+                                       T, N, _p(age), _stream(terminated)), "ppo_age_scan")
+    return age

@@ -1,0 +1,112 @@
+"""Actor-critic networks of the PPO path (PyTorch-ROCm: the conv / linear GEMMs run on MFMA via
+MIOpen / hipBLASLt; everything around them is HIP, see ppo_ops.py).
+
+Architecture, state_dict key names and the initialisation scheme are those of the reference
+(soa/agent/net/all_net.py:139-304) so that checkpoints are interchangeable and, under the same
+torch seed, freshly built networks are bit-identical (tests/test_nets.py):
+
+  TINet        frames (B,F,289) -> view (B,F,17,17) -> nearest x4 (B,F,68,68)
+               -> conv(F->64,k4,s2) 33^2 -> conv(64->64,k3,s2) 16^2 -> conv(64->128,k4,s2) 7^2
+               -> conv(128->256,k3,s2) 3^2 -> flatten 2304 -> fc0 256 ;   all ReLU
+               coords (B,4,2)+(B,2) -> Linear(10,128) ; cat 384 -> fc1 512
+  actor        bone1 = TINet, A = Linear(512,5), softmax          (keys bone1.*, A.*)
+  critic       bone2 = TINet, V = Linear(512,1)                   (keys bone2.*, V.*)
+  predictor variants: first conv takes 8 frames (4 real + 4 predicted), all_net.py:249-304.
+
+Init (all_net.py:162-172, applied by TINet and again by the wrapper): Linear xavier-normal / bias 0,
+Conv2d xavier-uniform(gain=sqrt 2) / bias 0.1.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+GRID = 17
+CELLS = GRID * GRID
+
+
+def reference_init(m):
+    """The reference's `_weights_init` rule (identical in every network class)."""
+    if isinstance(m, nn.Linear):
+        nn.init.xavier_normal_(m.weight)
+        nn.init.constant_(m.bias, 0)
+    elif isinstance(m, nn.Conv2d):
+        nn.init.xavier_uniform_(m.weight, gain=math.sqrt(2.0))
+        nn.init.constant_(m.bias, 0.1)
+    elif isinstance(m, nn.BatchNorm2d):
+        nn.init.constant_(m.weight, 1)
+        nn.init.constant_(m.bias, 0)
+
+
+def _conv_stack(in_frames):
+    spec = [(in_frames, 64, 4), (64, 64, 3), (64, 128, 4), (128, 256, 3)]
+    layers = []
+    for cin, cout, k in spec:
+        layers += [nn.Conv2d(cin, cout, kernel_size=k, stride=2), nn.ReLU()]
+    layers.append(nn.Flatten())
+    return nn.Sequential(*layers)
+
+
+class TINet(nn.Module):
+    """Frame-stack + coordinate encoder shared by actor and critic (512-d feature)."""
+
+    def __init__(self):
+        super().__init__()
+        # construction order == reference order: it fixes both the state_dict order and the
+        # torch-RNG consumption of the default initialisers that run before reference_init
+        self.cnn_base = _conv_stack(4)
+        self.positionnet = nn.Linear(10, 128)
+        self.fc0 = nn.Linear(2304, 256)
+        self.fc1 = nn.Linear(256 + 128, 512)
+        self.upsamplingnearest = nn.UpsamplingNearest2d(scale_factor=4)
+        self.apply(reference_init)
+
+    def widen_input(self, in_frames):
+        """Swap the first conv for an `in_frames`-channel one (predictor variants, all_net.py:255,284)."""
+        self.cnn_base[0] = nn.Conv2d(in_frames, 64, kernel_size=4, stride=2)
+
+    def forward(self, state_matrix, position, goal):
+        B, F, _ = state_matrix.shape
+        coords = torch.cat([position.contiguous().view(B, -1), goal], dim=1)
+        coords = torch.relu(self.positionnet(coords))
+        img = self.upsamplingnearest(state_matrix.contiguous().view(B, F, GRID, GRID))
+        feat = torch.relu(self.fc0(self.cnn_base(img)))
+        return torch.relu(self.fc1(torch.cat([feat, coords], dim=1)))
+
+
+class _Head(nn.Module):
+    bone_name, head_name, head_out, in_frames = "", "", 0, 4
+
+    def __init__(self):
+        super().__init__()
+        bone = TINet()
+        if self.in_frames != 4:
+            bone.widen_input(self.in_frames)
+        setattr(self, self.bone_name, bone)
+        setattr(self, self.head_name, nn.Linear(512, self.head_out))
+        self.apply(reference_init)
+
+    def features(self, state_matrix, position, goal):
+        return getattr(self, self.bone_name)(state_matrix, position, goal)
+
+
+class Net_PPO_actor(_Head):
+    bone_name, head_name, head_out = "bone1", "A", 5
+
+    def forward(self, state_matrix, position, goal, model="actor"):
+        return torch.softmax(self.A(self.features(state_matrix, position, goal)), dim=1)
+
+
+class Net_PPO_critic(_Head):
+    bone_name, head_name, head_out = "bone2", "V", 1
+
+    def forward(self, state_matrix, position, goal, model="actor"):
+        return self.V(self.features(state_matrix, position, goal))
+
+
+class Net_PPO_Predictor_actor(Net_PPO_actor):
+    in_frames = 8
+
+
+class Net_PPO_Predictor_critic(Net_PPO_critic):
+    in_frames = 8

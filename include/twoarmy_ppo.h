@@ -1,0 +1,79 @@
+/*
+ * twoarmy_ppo.h -- C ABI of the PPO math kernels (libtwoarmy_hip.so, <package>/csrc/ppo_kernels.hip).
+ *
+ * Replaces, for batches of B samples resident in HBM, the torch ops of the reference's
+ * soa/agent/PPO.py (paths relative to the reference root):
+ *   select_action  PPO.py:73-92    Categorical(probs).sample() / log_prob        -> ppo_sample
+ *   update         PPO.py:112-115  target_v = r + g*V(s'), adv = target_v - V(s) -> ppo_gae (lambda = 0, no mask)
+ *                  PPO.py:115      (commented) adv = (adv - mean) / (std + 1e-8) -> ppo_adv_norm
+ *                  PPO.py:124-133  ratio-clip surrogate + entropy, SmoothL1      -> ppo_loss_fwd_bwd
+ *   train_ppo.py:116-123  5-frame stack shift + store                            -> ppo_gather_stack
+ * GAE(gamma, lambda) with done masks has no reference counterpart: it collapses to the
+ * reference formula at lambda = 0, use_done_mask = 0 and is otherwise pinned by oracle/ppo_oracle.py only.
+ *
+ * Conventions as in twoarmy.h: device pointers, caller-owned, `stream` = hipStream_t as void*,
+ * asynchronous, 0 = ok / negative = TW_E_*.  All tensors fp32 unless noted; time-major [T][N].
+ */
+#ifndef TWOARMY_PPO_H
+#define TWOARMY_PPO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* torch.distributions.Categorical(probs=p) semantics: q = p / sum(p); logits = log(clamp(q, eps, 1-eps)),
+ * eps = FLT_EPSILON; log_prob(a) = logits[a].  Sampling is inverse-CDF on q with a supplied uniform
+ * u in [0,1): a = min{k : cumsum(q)[k] > u} (clamped to A-1).  uniforms == NULL -> u from
+ * Philox4x32-10(key = seed, counter = (lo32(row + offset), hi32(row + offset), 0, 'TWOS')),
+ * u = (word0 >> 8) * 2^-24.
+ *   probs float[B][A] (A <= 8), uniforms float[B]|NULL, action int32[B], logp float[B] */
+int ppo_sample(const float *probs, int B, int A, const float *uniforms, uint64_t seed, uint64_t offset,
+               int32_t *action, float *logp, void *stream);
+
+/* delta_t = r_t + gamma * nv_t * cut_t - v_t;  A_t = delta_t + gamma*lambda*cut_t*A_{t+1} (A_T = 0);
+ * cut_t = use_done_mask ? 1 - done_t : 1.  Outputs (each nullable): adv = A, target = r + gamma*nv*cut
+ * (the reference's target_v), ret = A + v.  Segmented reverse scan: one wavefront scans 64 time steps of
+ * one env with 6 shuffle steps over affine maps; [T][N] tiles are transposed through LDS.
+ *   reward, value, next_value float[T][N]; done uint8[T][N] (nullable when !use_done_mask) */
+int ppo_gae(const float *reward, const float *value, const float *next_value, const uint8_t *done,
+            float gamma, float lambda, int use_done_mask, int T, int N, float *adv, float *target, float *ret,
+            void *stream);
+
+/* adv <- (adv - mean) / (std + eps), std unbiased (torch.Tensor.std default).  workspace: >= 4096 doubles. */
+int ppo_adv_norm(float *adv, int64_t n, float eps, double *workspace, void *stream);
+
+/* Fused forward + backward of the reference losses (PPO.py:124-133) for one minibatch:
+ *   action_loss = mean(-min(ratio*adv, clamp(ratio, 1-clip, 1+clip)*adv) - ent_coef * H),
+ *   value_loss  = smooth_l1(value, target_v)  (beta = 1, mean)
+ * with ratio = exp(logp(a) - old_logp) and Categorical(probs) semantics as in ppo_sample.
+ * Writes losses[0] = action_loss, losses[1] = value_loss, d(action_loss)/d(probs) float[B][A] and
+ * d(value_loss)/d(value) float[B].  Deterministic (fixed-order two-stage reduction).
+ * workspace: >= 2 * ceil(B/256) floats. */
+int ppo_loss_fwd_bwd(const float *probs, const int32_t *action, const float *old_logp, const float *adv,
+                     const float *value, const float *target_v, int B, int A, float clip, float ent_coef,
+                     float *losses, float *grad_probs, float *grad_value, float *workspace, void *stream);
+
+/* Policy-input assembly from time-major frames (replaces the 5-deep np.delete/np.append stacks of
+ * train_ppo.py:116-121 and the [0:4] / [1:5] slices of PPO.py:113-114,124).  For sample b with newest
+ * frame index k_b (row of `frames`), env n_b and age_b = number of env steps taken in the current
+ * episode when that newest frame was produced:
+ *   out[b][j] = (age_b - (3 - j) <= 0) ? init_frame : frames[k_b - (3 - j)][n_b]      j = 0..3
+ * i.e. the four newest frames, never crossing the episode start: older slots repeat the reset frame
+ * exactly as np.tile does in Env_transact.reset (env_buffer.py:420-423).  Same for the (y,x) stacks.
+ *   frames float[K][N][frame_pitch]; pos_frames float[K][N][2]; k_idx, n_idx, age int32[B];
+ *   init_frame float[289]; init_pos float[2]; out float[B][4][289]; pos_out float[B][4][2] (nullable) */
+int ppo_gather_stack(const float *frames, int frame_pitch, const float *pos_frames, int N,
+                     const int32_t *k_idx, const int32_t *n_idx, const int32_t *age, const float *init_frame,
+                     const float *init_pos, int B, float *out, float *pos_out, void *stream);
+
+/* Episode age before every step of a rollout: age[0][n] = age0[n]; age[t+1][n] = done[t][n] ? 0 : age[t][n]+1.
+ *   done uint8[T][N] (terminated | truncated), age0 int32[N], age int32[T+1][N] */
+int ppo_age_scan(const uint8_t *terminated, const uint8_t *truncated, const int32_t *age0, int T, int N,
+                 int32_t *age, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TWOARMY_PPO_H */

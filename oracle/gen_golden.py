@@ -269,7 +269,175 @@ def gen_views():
     print("views: %d cases x 4 sizes -> %s (%.1f KB)" % (len(grids), path_out, os.path.getsize(path_out) / 1024))
 
 
-STAGES = {"traces": gen_traces, "views": gen_views}
+# ----------------------------------------------------------------------------- PPO
+def det_weights(module, seed):
+    """Deterministic, torch-RNG-free weights: w[i] = scale * sin(0.37 * i + k + seed), scale ~ xavier."""
+    import torch
+    sd = {}
+    for k, (name, prm) in enumerate(module.state_dict().items()):
+        n = prm.numel()
+        fan = max(1, n // prm.shape[0]) if prm.dim() > 1 else 1
+        scale = (1.5 / np.sqrt(fan)) if prm.dim() > 1 else 0.05
+        v = scale * np.sin(0.37 * np.arange(n, dtype=np.float64) + 1.7 * k + seed)
+        sd[name] = torch.tensor(v.reshape(tuple(prm.shape)), dtype=prm.dtype)
+    return sd
+
+
+def param_stats(module):
+    out = []
+    for name, prm in module.state_dict().items():
+        v = prm.detach().double().reshape(-1)
+        out.append((name, tuple(prm.shape), float(v.sum()), float(v.abs().sum()), v[:4].tolist()))
+    return out
+
+
+def collect_buffer(env_buffer, variant, n_records, seed):
+    """Fill a Buffer_gridworld exactly like soa/train_ppo.py:93-123 with a seeded random policy (HER off)."""
+    buf = env_buffer.Buffer_gridworld()
+    buf.grid_size = 17
+    buf.transition = np.dtype([('s', np.float32, (5, 289)), ('a', np.int64, (1,)), ('p', np.float32, (5, 2)),
+                               ('g', np.float32, (2,)), ('r', np.float32, (1,)), ('d', np.float32, (1,)),
+                               ('a_logp', np.float32, (1,))])
+    buf.buffer_capacity = n_records
+    buf.buffer = np.empty(n_records, dtype=buf.transition)
+    rs = np.random.RandomState(seed)
+    slots = PhiloxSlots(SEED, 700 + seed)
+    rec = rh.SlotRecorder(slots)
+
+    class Args:
+        server = True
+
+    class Win:
+        def set_caption(self, *_):
+            pass
+
+        def show_img(self, *_):
+            pass
+    t = 0
+    with rh.patched_choice(rec):
+        env = rh.make_env(variant)
+        while not buf.full:
+            et = env_buffer.Env_transact()
+            sm_stack, st_stack, goal = et.reset(env, Win())
+            for _ in range(10000):
+                a_idx = int(rs.choice(5, p=(0.1, 0.3, 0.35, 0.1, 0.15)))
+                logp = float(np.log(0.2) - 0.01 * rs.rand())
+                action = et.env_action(env, a_idx)
+                slots.begin_step(t)
+                t += 1
+                _, r, term, trunc, done = et.step(env, None, action, Args)
+                state, goal = et.data_env(env)
+                st_stack = np.append(np.delete(st_stack, 0, 0), [state], 0)
+                sm_stack = np.append(np.delete(sm_stack, 0, 0), [et.matrix_env(env)], 0)
+                buf.store((np.array(sm_stack, dtype='float32'), np.array([a_idx], dtype='int64'),
+                           np.array(st_stack, dtype='float32'), np.array(goal, dtype='float32'),
+                           np.array([r], dtype='float32'), np.array([done], dtype='int64'),
+                           np.array([logp], dtype='float32')))
+                if term or trunc or buf.full:
+                    break
+    return buf
+
+
+def gen_ppo():
+    """soa/agent/PPO.py + soa/agent/net/all_net.py: init statistics, forward, log-prob/entropy, update losses."""
+    import torch
+    env_buffer, ppo_mod = rh.soa_modules()
+    from agent.net.all_net import Net_PPO_actor, Net_PPO_critic
+    out = {}
+    # (1) init parity: same construction order as PPO.__init__ (PPO.py:46-47) under torch.manual_seed
+    torch.manual_seed(SEED)
+    actor, critic = Net_PPO_actor(), Net_PPO_critic()
+    for tag, net in (("actor", actor), ("critic", critic)):
+        st = param_stats(net)
+        out["init_%s_names" % tag] = np.array([x[0] for x in st])
+        out["init_%s_sum" % tag] = np.array([x[2] for x in st])
+        out["init_%s_abs" % tag] = np.array([x[3] for x in st])
+        out["init_%s_head" % tag] = np.array([x[4] + [0.0] * (4 - len(x[4])) for x in st])
+        out["init_%s_numel" % tag] = np.array([int(np.prod(x[1])) for x in st])
+    # (2) forward / distribution parity with injected deterministic weights
+    buf = collect_buffer(env_buffer, "v6", 64, seed=3)
+    b = buf.buffer
+    actor.load_state_dict(det_weights(actor, 1))
+    critic.load_state_dict(det_weights(critic, 2))
+    actor.eval(); critic.eval()
+    s = torch.tensor(b['s'][:12]); pp = torch.tensor(b['p'][:12]); g = torch.tensor(b['g'][:12])
+    with torch.no_grad():
+        probs = actor(s[:, 1:5], pp[:, 1:5], g)
+        val = critic(s[:, 1:5], pp[:, 1:5], g)
+        dist = torch.distributions.Categorical(probs=probs)
+        a = torch.tensor(b['a'][:12, 0])
+        out["fwd_probs"] = probs.numpy(); out["fwd_value"] = val.numpy()
+        out["fwd_logp"] = dist.log_prob(a).numpy(); out["fwd_entropy"] = dist.entropy().numpy()
+        out["fwd_logits_all"] = dist.logits.numpy()
+    # (3) PPO.update: 64 records, batch 16, K_epochs 2 (PPO.py:103-161)
+    agent = ppo_mod.PPO()
+    agent.actor.load_state_dict(det_weights(agent.actor, 1))
+    agent.critic.load_state_dict(det_weights(agent.critic, 2))
+    agent.batch_size = 16
+    agent.K_epochs = 2
+    agent.heatmapfilename = "x"
+    torch.manual_seed(123)
+    perm_state = torch.get_rng_state()
+    agent.update(b, torch.device("cpu"), 0)
+    out["upd_action_loss"] = np.array([v for _, v in agent.writer.scalars["loss/action_loss_update"]])
+    out["upd_value_loss"] = np.array([v for _, v in agent.writer.scalars["loss/value_loss_update"]])
+    for tag, net in (("actor", agent.actor), ("critic", agent.critic)):
+        st = param_stats(net)
+        out["upd_%s_sum" % tag] = np.array([x[2] for x in st])
+        out["upd_%s_abs" % tag] = np.array([x[3] for x in st])
+    # the minibatch permutations torch drew (SubsetRandomSampler == randperm per epoch)
+    torch.set_rng_state(perm_state)
+    out["upd_perms"] = np.stack([torch.randperm(64).numpy() for _ in range(2)])
+    for k in ('s', 'a', 'p', 'g', 'r', 'd', 'a_logp'):
+        out["buf_" + k] = b[k]
+    out["hyper"] = np.array([agent.gamma, agent.clip_param, agent.entropy_coef, 1e-4, 1e-5])
+    path_out = os.path.join(GOLD, "ppo.npz")
+    np.savez_compressed(path_out, **out)
+    print("ppo: losses", out["upd_action_loss"][:3], out["upd_value_loss"][:3], "-> %s (%.1f KB)"
+          % (path_out, os.path.getsize(path_out) / 1024))
+
+
+# ----------------------------------------------------------------------------- HER
+def gen_her():
+    """Buffer_gridworld.her_func (soa/env_buffer.py:101-143) on recorded episodes, incl. ring wrap."""
+    env_buffer, _ = rh.soa_modules()
+    out = {}
+    cases = [dict(cap=64, seed=0, pre=0), dict(cap=64, seed=1, pre=17), dict(cap=40, seed=2, pre=25),
+             dict(cap=48, seed=5, pre=30), dict(cap=64, seed=7, pre=3)]
+    for ci, c in enumerate(cases):
+        buf = collect_buffer(env_buffer, "v6", 256, seed=10 + ci)     # source of realistic records
+        src = buf.buffer
+        # one full episode = records from index 0 to the first done/truncation boundary (p stack restarts)
+        # find episode end: next record whose stack is 5 identical positions shifted once
+        L = 1
+        while L < 60 and not (src['p'][L][0] == src['p'][L][1]).all():
+            L += 1
+        ep = src[:L].copy()
+        b2 = env_buffer.Buffer_gridworld()
+        b2.grid_size = 17
+        b2.transition = src.dtype
+        b2.buffer_capacity = c["cap"]
+        b2.buffer = np.zeros(c["cap"], dtype=src.dtype)
+        b2.counter = c["pre"]
+        b2.epo_counter_start = c["pre"]
+        for r in ep:
+            b2.store(r)
+        before = b2.buffer.copy()
+        cnt_before, full_before = b2.counter, b2.full
+        np.random.seed(c["seed"])
+        b2.her_func(max_steps=50, newgoal_size_in=4)
+        for k in src.dtype.names:
+            out["c%d_before_%s" % (ci, k)] = before[k]
+            out["c%d_after_%s" % (ci, k)] = b2.buffer[k]
+        out["c%d_meta" % ci] = np.array([c["cap"], c["seed"], c["pre"], L, cnt_before, int(full_before),
+                                         b2.counter, int(b2.full), b2.epo_counter_end])
+    out["n_cases"] = np.int32(len(cases))
+    path_out = os.path.join(GOLD, "her.npz")
+    np.savez_compressed(path_out, **out)
+    print("her: %d cases -> %s (%.1f KB)" % (len(cases), path_out, os.path.getsize(path_out) / 1024))
+
+
+STAGES = {"traces": gen_traces, "views": gen_views, "ppo": gen_ppo, "her": gen_her}
 
 
 def main(argv):
