@@ -1,0 +1,111 @@
+"""Env adapter + replay buffer of the PPO path (reference soa/env_buffer.py).
+
+`Env_transact` keeps the reference's method names and return shapes (matrix_env, data_env,
+env_action, reset, step) on top of the facade env; the state matrix comes from the HIP kernel's fused
+output instead of a Python loop over 289 cells.  `Buffer_gridworld` is the numpy ring buffer with the
+reference's store() and hindsight relabelling her_func() (env_buffer.py:68-77, 101-143) -- host logic,
+identical index arithmetic, checked against tests/golden/her.npz.
+"""
+import numpy as np
+
+
+class Buffer_gridworld:
+    def __init__(self):
+        self.name = None
+        self.grid_size = None
+        self.transition = None
+        self.buffer_capacity = 100000
+        self.buffer = []
+        self.counter = 0
+        self.full = False
+        self.epo_counter_start = 0
+        self.epo_counter_end = 0
+
+    @staticmethod
+    def ppo_dtype(grid_size=17):
+        """Record layout of soa/train_ppo.py:93-97."""
+        return np.dtype([("s", np.float32, (5, grid_size ** 2)), ("a", np.int64, (1,)), ("p", np.float32, (5, 2)),
+                         ("g", np.float32, (2,)), ("r", np.float32, (1,)), ("d", np.float32, (1,)),
+                         ("a_logp", np.float32, (1,))])
+
+    def store(self, transition):
+        if self.counter >= self.buffer_capacity:
+            self.counter, self.full = 0, True
+        self.buffer[self.counter] = transition
+        self.counter += 1
+        if self.counter == self.buffer_capacity:
+            self.counter, self.full = 0, True
+        return self.full
+
+    def her_func(self, max_steps=50, newgoal_size_in=4):
+        """Hindsight relabelling of the episode [epo_counter_start, counter): for up to 4 distinct
+        first-visit positions (np.random.choice without replacement, global numpy RNG like the
+        reference) append the prefix that reaches it with g := achieved (y,x), last r := 0.9, d := 1."""
+        cap = self.buffer_capacity
+        end = self.counter - 1
+        episode = self.buffer[self.epo_counter_start:end + 1].copy()
+        _, first_visit = np.unique(episode["p"][:, 4, 0:2], return_index=True, axis=0)
+        k = min(newgoal_size_in, first_visit.size)
+        if end - self.epo_counter_start + 1 > 0:
+            for index in np.random.choice(first_visit, size=k, replace=False):
+                if not (0 < index < cap):
+                    continue
+                prefix = episode[:index + 1].copy()
+                prefix["g"][:] = prefix["p"][index, 4, 0:2]
+                prefix["r"][index] = 0.9
+                prefix["d"][index] = 1
+                n = index + 1
+                if end + 1 + n <= cap:
+                    self.buffer[end + 1:end + 1 + n] = prefix
+                    end += n
+                else:                                   # wrap around the ring
+                    over = end + 1 + n - cap
+                    self.buffer[end + 1:cap] = prefix[:n - over]
+                    self.buffer[:over] = prefix[n - over:]
+                    end = over - 1
+                    self.full = True
+        self.epo_counter_end = end
+        self.counter = end + 1
+
+
+class Env_transact:
+    def __init__(self):
+        self.name = None
+        self.grid = None
+        self.size_agentob = 17 ** 2
+        self.state_matrix = np.full((self.size_agentob,), 0.9)
+        self.runstep = 0
+
+    def matrix_env(self, env):
+        """0.9 free / goal, -0.9 wall, -0.5 ball, 0.3 agent (env_buffer.py:300-318)."""
+        self.grid = env.grid
+        t = env.grid._t.reshape(-1)
+        m = np.where(t == 2, -0.9, np.where(t == 6, -0.5, 0.9))
+        i, j = env.agent_pos
+        m[env.grid.height * j + i] = 0.3
+        self.state_matrix = m
+        return m
+
+    def data_env(self, env):
+        (i, j), (gi, gj) = env.agent_pos, env.goal_pos
+        return np.array((j, i), dtype=float), np.array((gj, gi), dtype=float)
+
+    def env_action(self, env, action_agent):
+        a = env.actions
+        return {0: a.left, 1: a.right, 2: a.up, 3: a.down, 4: a.done}.get(action_agent)
+
+    def reset(self, env, window=None):
+        env.reset()
+        state_matrix = self.matrix_env(env)
+        state, goal = self.data_env(env)
+        return np.tile(state_matrix, (5, 1)), np.tile(state, (5, 1)), goal
+
+    def step(self, env, window, action, args=None):
+        self.runstep += 1
+        obs, reward, terminated, truncated, _ = env.step(action)
+        done = 0
+        if self.runstep > 49:
+            truncated = True
+        if terminated:
+            done, reward = 1, 0.9
+        return obs, reward, terminated, truncated, done

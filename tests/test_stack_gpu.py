@@ -1,0 +1,112 @@
+"""Facade env, VecEnv and the vectorised rollout storage on the GPU."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import load_traces
+
+pytestmark = pytest.mark.gpu
+TRACES, SEED = load_traces()
+
+
+@pytest.mark.parametrize("idx", [0, 3, 4, 6, 12, 17, 24, 30, 38])
+def test_facade_env_replays_reference_traces(idx):
+    """gym_minigrid facade (MiniGridEnv API) + Env_transact on recorded reference traces."""
+    from twoarmy_amd.gym_minigrid import make
+    from twoarmy_amd.soa.env_buffer import Env_transact
+    tr = TRACES[idx]
+    if int(tr["natural"]):
+        pytest.skip("natural-stream traces need explicit draws (covered by test_engine_gpu)")
+    env = make("MiniGrid-twoarmy-17x17-v%d" % int(tr["variant"]), seed=SEED, env_id=int(tr["env_id"]), tile_size=17)
+    et = Env_transact()
+    errs = {1: AttributeError, 2: AssertionError, 3: TypeError}
+    for k, op in enumerate(tr["op"]):
+        ctx = "%s op#%d=%d" % (tr["name"], k, op)
+        if op == -1:
+            obs = env.reset()
+            assert np.array_equal(obs["image"], tr["obs"][k]), ctx
+        elif int(tr["err"][k]):
+            with pytest.raises(errs[int(tr["err"][k])]):
+                env.step(int(op))
+        else:
+            obs, r, te, trn, info = env.step(int(op))
+            assert np.array_equal(obs["image"], tr["obs"][k]) and obs["direction"] == 3, ctx
+            assert r == float(tr["reward"][k]) and te == bool(tr["term"][k]) and trn == bool(tr["trunc"][k]), ctx
+        assert env.agent_pos == tuple(tr["agent"][k]) and env.step_count == int(tr["scal"][k][0]), ctx
+        assert np.array_equal(env.grid.encode(), tr["grid"][k]), ctx
+        assert np.array_equal(et.matrix_env(env), tr["matrix"][k]), ctx
+        a, g = et.data_env(env)
+        assert np.concatenate([a, g]).tolist() == tr["pos"][k].tolist(), ctx
+        assert [o.cur_pos for o in env.obstacles] == [tuple(p) for p in tr["balls"][k]], ctx
+    assert env.action_space.n == 7 and env.actions.done == 6 and et.env_action(env, 4) == 6
+    env.close()
+
+
+def test_vecenv_autoreset_semantics():
+    from twoarmy_amd.vecenv import TwoarmyVecEnv
+    env = TwoarmyVecEnv("MiniGrid-twoarmy-17x17-v6", num_envs=256, seed=SEED)
+    obs0 = env.reset().clone()
+    assert obs0.shape == (256, 17, 17, 3) and bool((obs0 == obs0[0]).all())
+    saw_done = 0
+    for t in range(60):
+        a = torch.full((256,), 2 if t % 3 else 1, dtype=torch.int64, device=env.device)     # right / up
+        obs, r, te, tr, info = env.step(a)
+        done = te | tr
+        if bool(done.any()):
+            saw_done += int(done.sum())
+            assert bool((obs[done] == obs0[0]).all())                  # next-episode observation
+            assert not bool((info["final_observation"][done] == obs0[0]).all())
+        assert env.state_matrix.shape == (256, 289) and env.agent_yx.shape == (256, 2)
+    assert saw_done > 0
+    env.close()
+
+
+def test_rollout_stacks_equal_reference_style_stacks():
+    """The on-the-fly 4-frame stacks (frames + age + ppo_gather_stack) equal the literal 5-deep
+    np.delete/np.append stacks of soa/train_ppo.py:104-121 for every (t, n)."""
+    from twoarmy_amd.engine import TwoarmyEngine
+    from twoarmy_amd.soa.agent.PPO import PPO
+    from twoarmy_amd.soa.ppo_vec import VecPPOTrainer
+    torch.manual_seed(0)
+    N, T = 48, 70
+    eng = TwoarmyEngine(6, N, 17, seed=SEED)
+    agent = PPO()
+    tr = VecPPOTrainer(agent, eng, rollout_steps=T, minibatch=256)
+    uni = torch.rand(T, N, device=tr.device)
+    tr.collect(uniforms=uni)
+    torch.cuda.synchronize()
+    frames = tr.frames.cpu().numpy(); pos = tr.pos.cpu().numpy()
+    done = ((tr.term | tr.trunc) != 0).cpu().numpy()
+    init_f, init_p = tr.init_frame.cpu().numpy(), np.array([15.0, 3.0], np.float32)
+    # literal stacks, one env at a time
+    lit_s = np.zeros((T, N, 5, 289), np.float32); lit_p = np.zeros((T, N, 5, 2), np.float32)
+    for n in range(N):
+        s = np.tile(init_f, (5, 1)); p = np.tile(init_p, (5, 1))
+        for t in range(T):
+            s = np.append(np.delete(s, 0, 0), [frames[t + 4, n]], 0)
+            p = np.append(np.delete(p, 0, 0), [pos[t + 4, n]], 0)
+            lit_s[t, n], lit_p[t, n] = s, p
+            if done[t, n]:
+                s = np.tile(init_f, (5, 1)); p = np.tile(init_p, (5, 1))
+    idx = torch.arange(T * N, device=tr.device)
+    s0, p0 = tr._stacks(idx // N, idx % N, after=False)
+    s1, p1 = tr._stacks(idx // N, idx % N, after=True)
+    assert np.array_equal(s0.cpu().numpy().reshape(T, N, 4, 289), lit_s[:, :, 0:4])
+    assert np.array_equal(s1.cpu().numpy().reshape(T, N, 4, 289), lit_s[:, :, 1:5])
+    assert np.array_equal(p0.cpu().numpy().reshape(T, N, 4, 2), lit_p[:, :, 0:4])
+    assert np.array_equal(p1.cpu().numpy().reshape(T, N, 4, 2), lit_p[:, :, 1:5])
+    assert done.sum() > 0
+    # and one optimisation pass runs end to end
+    agent.K_epochs = 1
+    la, lv = tr.update()
+    assert np.isfinite(float(la)) and np.isfinite(float(lv))
+    tr.carry_over()
+    tr.collect()
+    eng.close()
+
+
+def test_train_ppo_entry_point_smoke():
+    from twoarmy_amd.soa import train_ppo
+    tr = train_ppo.main(["--env", "MiniGrid-twoarmy-17x17-v4", "--num_envs", "64", "--rollout_steps", "16",
+                         "--minibatch", "256", "--updates", "2", "--k_epochs", "1", "--cuda", "cuda:0"])
+    assert tr.env_steps == 2 * 16 * 64
