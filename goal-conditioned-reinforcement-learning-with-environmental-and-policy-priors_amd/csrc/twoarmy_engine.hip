@@ -184,6 +184,14 @@ __device__ __forceinline__ void reset_scalars(EnvS &s) {
     s.step_count = 0; s.err = 0;
 }
 
+// Invariants of the kernel's TURBO step (see tw_rollout_kernel): the three row-8 balls are an adjacent
+// triple well inside the grid, the agent faces up and stands strictly inside the border.
+__device__ __forceinline__ bool normal_mode(const EnvS &s) {
+    return (s.oby[0] == 8) & (s.oby[1] == 8) & (s.oby[2] == 8) & (s.obx[1] == s.obx[0] + 1) &
+           (s.obx[2] == s.obx[0] + 2) & ((unsigned)(s.obx[0] - 2) <= 10u) & (s.dir == 3) &
+           ((unsigned)(s.ax - 1) <= 14u) & ((unsigned)(s.ay - 1) <= 14u);
+}
+
 __device__ __forceinline__ bool inb(int x, int y) { return (unsigned)x < (unsigned)GS && (unsigned)y < (unsigned)GS; }
 __device__ __forceinline__ int gpi(int x, int y) { return (y + GPY0) * GPW + x + GPX0; }
 
@@ -373,6 +381,16 @@ __device__ __forceinline__ void regen_env(uint32_t *env, int lane) {
     }
 }
 
+#ifdef TW_STAMP
+// Diagnostic build only (make stamp): phase cycle shares via s_memtime; never in the shipped library.
+__device__ unsigned long long g_stamp[64][8];
+#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long _t; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); \
+    st_acc[i] += _t - st_prev; st_prev = _t; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------- the rollout kernel
 // FAST = every output present, native 16-byte layouts, actions supplied, Philox draws: all the
 // wave-uniform "is this pointer null / is this layout aligned" branches fold away at compile time.
@@ -422,6 +440,7 @@ __global__ __launch_bounds__(64, (E == 1 ? 4 : 2)) void tw_rollout_kernel(Params
     wave_sync();
     EnvS s;
     load_env(s, recs + (lane < E ? lane : 0) * REC);
+    bool mode_ok = normal_mode(s);
 
     const int V = p.view;
     const int obs_chunk_bytes = ((V * V * 3 + 15) >> 4) << 4;
@@ -443,7 +462,12 @@ __global__ __launch_bounds__(64, (E == 1 ? 4 : 2)) void tw_rollout_kernel(Params
     const size_t obs_step = (size_t)N * p.obs_pitch, mat_step = (size_t)N * p.mat_pitch;
     size_t idx = (size_t)n0 + lane;                         // [t][n] row of this lane's env
 
+#ifdef TW_STAMP
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev) :: "memory");
+#endif
     for (int tt = 0; tt < p.T; ++tt, idx += N, obs_row += obs_step, mat_row += mat_step) {
+        STAMP(0);
 
         // ---- actions: one coalesced-per-env vector load every 64 steps, parked in LDS
         if (has_actions && (tt & 63) == 0) {
@@ -456,12 +480,13 @@ __global__ __launch_bounds__(64, (E == 1 ? 4 : 2)) void tw_rollout_kernel(Params
             wave_sync();
         }
 
+        STAMP(1);
         // ================= LOGIC part 1 (lane-per-env): everything before gen_obs()
         int err = TW_ENV_OK, have_obs = 0, terminated = 0, truncated = 0, reward = R_STEP;
         uint32_t dw[4] = {0, 0, 0, 0};                      // draw block 0: gate, wall1, wall2, spawn
         const uint32_t t_now = s.t;
+        int action = 0;
         if (active) {
-            int action;
             if (has_actions) action = act_lds[(tt & 63) * E + lane];
             else {
                 uint32_t w[4];
@@ -477,8 +502,84 @@ __global__ __launch_bounds__(64, (E == 1 ? 4 : 2)) void tw_rollout_kernel(Params
                     draw_block(p.seed_lo, p.seed_hi, env_id, t_now, 0, dw);
                 }
             }
-            s.t += 1;
             if (action >= 7) action = 0;                          // twoarmy_v6.py:85-86
+        }
+        // TURBO step: every env of the wave is in normal play (mode_ok: adjacent ball triple on row 8 well
+        // inside the grid, facing up, agent inside the border -> nothing can raise) and got a legal action
+        // {left,right,up,down,done}.  Then the whole pre-observation transition is branch-free.
+        const bool legal = ((unsigned)action <= 6u) & (((0x4Fu >> (action & 7)) & 1u) != 0u);
+        const bool all_turbo = __ballot(active && !(mode_ok && legal)) == 0ull;
+        if (all_turbo) {
+            if (active) {
+                s.t += 1;
+                s.step_move += 1;                                 // twoarmy_v6.py:88
+                s.m6 = s.m6 == 5 ? 0 : s.m6 + 1;
+                s.m4 = (s.m4 + 1) & 3;
+                const int m6 = s.m6;
+                const int dxb = (m6 <= 1) ? 1 : (m6 <= 3 ? -1 : 0);   // :104-109
+                // row-8 balls (:96-112) as 4 branch-free cell writes
+                uint32_t *row8 = my_env + gpi(0, 8);
+                uint32_t *mrow8 = my_env + MAT_OFF + 8 * GS;
+                const int b0 = s.obx[0], nb = b0 + dxb;
+                const int cx = dxb > 0 ? b0 : b0 + 2;             // the vacated cell (a ball cell when dxb == 0)
+                row8[cx] = dxb != 0 ? C_EMPTY : C_BALL;
+                mrow8[cx] = dxb != 0 ? M_FREE : M_BALL;
+                row8[nb] = C_BALL; row8[nb + 1] = C_BALL; row8[nb + 2] = C_BALL;
+                mrow8[nb] = M_BALL; mrow8[nb + 1] = M_BALL; mrow8[nb + 2] = M_BALL;
+                s.obx[0] = nb; s.obx[1] = nb + 1; s.obx[2] = nb + 2;
+                bool alive = true;
+                if (V4) {
+                    if (s.upd_long) {                             // twoarmy_v4.py:115-144
+                        s.upd_horiz = 0;
+                        bool go = (s.m4 == 2) || (m6 == 3) || (m6 == 0);
+                        if (!go) go = (dw[TW_S_GATE] % 10u) == 6u;
+                        if (go && s.patrol) {
+                            if (s.up1) {
+                                alive = move_group<3>(my_env, s.o1x, s.o1y, s.o1v, 0, -1, err);
+                                if (alive && s.o1y[0] == 3) s.up1 = 0;
+                            } else {
+                                alive = move_group<3>(my_env, s.o1x, s.o1y, s.o1v, 0, 1, err);
+                                if (alive && s.o1y[2] == 7) s.up1 = 1;
+                            }
+                        }
+                    }
+                    if (alive && s.upd_horiz) {                   // twoarmy_v4.py:147-176
+                        s.upd_long = 0;
+                        bool go = (m6 != 1);
+                        if (!go) go = (dw[TW_S_GATE] % 10u) == 6u;
+                        if (go && s.patrol) {
+                            if (s.right2) {
+                                alive = move_group<4>(my_env, s.o2x, s.o2y, s.o2v, 1, 0, err);
+                                if (alive && s.o2x[3] == 11) s.right2 = 0;
+                            } else {
+                                alive = move_group<4>(my_env, s.o2x, s.o2y, s.o2v, -1, 0, err);
+                                if (alive && s.o2x[0] == 5) s.right2 = 1;
+                            }
+                        }
+                    }
+                }
+                if (alive) {
+                    // MiniGridEnv.step (minigrid.py:1333-1441): dx/dy packed as 2-bit fields (value+1) per action
+                    s.step_count += 1;
+                    const int tx = s.ax + (int)((0x1558u >> (2 * action)) & 3u) - 1;     // L,R,U,D,-,-,stay
+                    const int ty = s.ay + (int)((0x1585u >> (2 * action)) & 3u) - 1;
+                    const uint32_t cv = my_env[gpi(tx, ty)];
+                    const uint32_t ct = cv & 0xffu, cs = (cv >> 16) & 0xffu;
+                    const bool enter = ((ct < 12u) & ((0x0B0Au >> (ct & 15u)) & 1u)) | ((ct == 4u) & (cs == 0u));
+                    s.ax = enter ? tx : s.ax;
+                    s.ay = enter ? ty : s.ay;
+                    terminated = ct == 8u;
+                    truncated = s.step_count >= s.max_steps;      // :1436-1437
+                    have_obs = 1;
+                    // keep the invariants of the turbo step for the next one
+                    mode_ok = ((unsigned)(nb - 2) <= 10u) & ((unsigned)(s.ax - 1) <= 14u) & ((unsigned)(s.ay - 1) <= 14u);
+                } else {
+                    mode_ok = false;
+                }
+            }
+        } else if (active) {
+            // GENERAL step: literal transition with every bounds check / raise of the reference
+            s.t += 1;
             s.step_move += 1;                                     // :88
             s.m6 = s.m6 == 5 ? 0 : s.m6 + 1;
             s.m4 = (s.m4 + 1) & 3;
@@ -576,9 +677,10 @@ __global__ __launch_bounds__(64, (E == 1 ? 4 : 2)) void tw_rollout_kernel(Params
                     have_obs = 1;
                 }
             }
-            if (!have_obs) {       // the reference raised: state keeps the mutations made so far
-                s.err = err; s.last_reward = -1; s.last_term = 0; s.last_trunc = 0;
-            }
+            mode_ok = have_obs && normal_mode(s);
+        }
+        if (active && !have_obs) {     // the reference raised: state keeps the mutations made so far
+            s.err = err; s.last_reward = -1; s.last_term = 0; s.last_trunc = 0;
         }
         wave_sync();
 
@@ -612,9 +714,15 @@ __global__ __launch_bounds__(64, (E == 1 ? 4 : 2)) void tw_rollout_kernel(Params
             }
             // row-ball collision / proximity (twoarmy_v6.py:231-243), branch-free
             bool hit = false, risk = false;
+            if (all_turbo) {                                      // adjacent triple on row 8: one span test
+                const bool in_span = (unsigned)(s.ax - s.obx[0]) <= 2u;
+                hit = in_span & (s.ay == 8);
+                risk = in_span & (s.ay == 9);
+            } else {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) hit |= (s.ax == s.obx[k]) & (s.ay == s.oby[k]);
-            risk = (s.ay == s.oby[0] + 1) & ((s.ax == s.obx[0]) | (s.ax == s.obx[1]) | (s.ax == s.obx[2]));
+                for (int k = 0; k < 3; ++k) hit |= (s.ax == s.obx[k]) & (s.ay == s.oby[k]);
+                risk = (s.ay == s.oby[0] + 1) & ((s.ax == s.obx[0]) | (s.ax == s.obx[1]) | (s.ax == s.obx[2]));
+            }
             reward = hit ? R_HIT : reward;
             reward = risk ? R_RISK : reward;
             if (s.patrol) {                                       // :245-283 (dead in v6: patrol is never set)
@@ -669,6 +777,7 @@ __global__ __launch_bounds__(64, (E == 1 ? 4 : 2)) void tw_rollout_kernel(Params
             s.err = err;
         };
 
+        STAMP(2);
         // ---- wave-uniform path selection
         const bool cells2 = active && have_obs &&
                             ((!s.pone && (s.ax > 3 || s.ay < 14)) || (V4 && !s.patrol && s.ay <= 8) ||
@@ -696,7 +805,9 @@ __global__ __launch_bounds__(64, (E == 1 ? 4 : 2)) void tw_rollout_kernel(Params
                     mq[e][1] = *reinterpret_cast<const uint4 *>(env + MAT_OFF + 4 * qb);
                 }
             }
+            STAMP(3);
             part2(std::false_type{});
+            STAMP(4);
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const bool valid_e = n0 + e < N;
@@ -760,6 +871,7 @@ __global__ __launch_bounds__(64, (E == 1 ? 4 : 2)) void tw_rollout_kernel(Params
             }
         }
 
+        STAMP(5);
         // ================= auto-reset (soa/train_ppo.py:104): ballot of done envs, regenerate in place
         if (autoreset) {
             const unsigned long long dm = __ballot(done != 0);
@@ -768,12 +880,16 @@ __global__ __launch_bounds__(64, (E == 1 ? 4 : 2)) void tw_rollout_kernel(Params
 #pragma unroll
                 for (int e = 0; e < E; ++e)
                     if ((dm >> e) & 1ull) regen_env(lds_env + e * ENV_WORDS, lane);
-                if (done) reset_scalars(s);
+                if (done) { reset_scalars(s); mode_ok = true; }
                 wave_sync();
             }
         }
     }
 
+#ifdef TW_STAMP
+    STAMP(6);
+    if (lane == 0 && blockIdx.x < 64) for (int i = 0; i < 8; ++i) g_stamp[blockIdx.x][i] = st_acc[i];
+#endif
     // ---- write state back
     wave_sync();
     if (lane < E) store_env(s, recs + lane * REC);
@@ -857,6 +973,8 @@ __global__ void tw_fill_actions_kernel(Params p, int32_t *out) {
 
 int g_last_hip_error = 0;
 char g_last_error_msg[256] = "";
+
+
 
 }  // namespace
 
@@ -1081,6 +1199,12 @@ int tw_gen_obs(tw_engine *e, int view_size, uint8_t *obs, int obs_pitch, void *s
     HIP_TRY(hipGetLastError());
     return TW_OK;
 }
+
+#ifdef TW_STAMP
+int tw_debug_stamps(unsigned long long *out512) {
+    return hipMemcpyFromSymbol(out512, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 512) == hipSuccess ? 0 : -2;
+}
+#endif
 
 int tw_n_envs(const tw_engine *e) { return e ? e->n_envs : TW_E_ARG; }
 int tw_view_size(const tw_engine *e) { return e ? e->view : TW_E_ARG; }
