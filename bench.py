@@ -36,6 +36,16 @@ def algorithmic_bytes_per_env_step(view, rollout_t):
     return per_step + per_launch / float(rollout_t)
 
 
+def traffic_from_profile(variant, n_envs, rollout_t, view):
+    """HBM bytes per launch of the dominant kernel from the committed PMC profile of the SAME configuration
+    (a bench run cannot profile itself); None when the configuration differs from the profiled one."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if not (variant == "v6" and n_envs == 4096 and rollout_t == 128 and view == 17 and os.path.exists(path)):
+        return None
+    with open(path) as f:
+        return json.load(f)["traffic_bytes_per_launch"]
+
+
 def cpu_baseline(variant, n_envs, view):
     """CPU oracle ("port": oracle/twoarmy_oracle.c, single thread) on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -119,6 +129,7 @@ def main():
     k_ms = eng.time_rollout(T, out, actions=actions[:T], autoreset=True, iters=iters)
     bytes_per_launch = bpe * N * T
     achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
+    traffic = traffic_from_profile(args.variant, N, T, V)
     torch.cuda.synchronize()
 
     if rank == 0:
@@ -134,7 +145,9 @@ def main():
                        "outputs_per_step": "obs u8[N,V,V,3] + state_matrix f32[N,289] + pos f32[N,2] + reward f32 + term u8 + trunc u8",
                        "parallelism": "env-sharded x%d, no collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)"
+                                           if traffic is not None else None,
                          "kernel": "tw_rollout_kernel", "kernel_ms": k_ms, "launches_timed": iters,
                          "algorithmic_bytes_per_env_step": bpe, "bytes_per_launch": bytes_per_launch,
                          "survey_bytes_per_env_step": 2690, "us_per_env_batch_step": k_ms * 1e3 / T},
