@@ -87,14 +87,22 @@ class PPO:
         self.grad_sync = None                      # callable(list_of_params) for multi-GPU (dist.py)
 
     # ------------------------------------------------------------------ acting
+    def policy_input(self, frames4):
+        """Hook: what the networks consume for a 4-frame stack (the predictor variant appends 4 predicted frames)."""
+        return frames4
+
     @torch.no_grad()
     def act_batch(self, frames4, pos4, goal, uniforms=None):
         """frames4 [B,4,289], pos4 [B,4,2], goal [B,2] (device) -> (action int32[B], logp float[B])."""
         self.actor.eval()
-        probs = self.actor(frames4, pos4, goal)
+        probs = self.actor(self.policy_input(frames4), pos4, goal)
         a, logp = ppo_ops.sample(probs, uniforms, seed=self.sample_seed, offset=self.sample_count)
         self.sample_count += probs.shape[0]
         return a, logp
+
+    def to(self, device):
+        self.actor.to(device); self.critic.to(device)
+        return self
 
     def select_action(self, state_matrix, states_stack, goal, device):
         """Reference signature (PPO.py:73-92): 5-deep numpy stacks in, python (action, log-prob) out."""
@@ -114,8 +122,8 @@ class PPO:
         nv = torch.empty(n, device=s.device)
         for i in range(0, n, chunk):
             j = min(n, i + chunk)
-            nv[i:j] = self.critic(s[i:j, 1:5], p[i:j, 1:5], g[i:j]).view(-1)
-            v[i:j] = self.critic(s[i:j, 0:4], p[i:j, 0:4], g[i:j]).view(-1)
+            nv[i:j] = self.critic(self.policy_input(s[i:j, 1:5]), p[i:j, 1:5], g[i:j]).view(-1)
+            v[i:j] = self.critic(self.policy_input(s[i:j, 0:4]), p[i:j, 0:4], g[i:j]).view(-1)
         adv, target, _ = ppo_ops.gae(r.view(1, n).contiguous(), v.view(1, n), nv.view(1, n),
                                      None if done is None else done.view(1, n).contiguous(),
                                      gamma=self.gamma, lam=0.0, use_done_mask=False, want_ret=False)
@@ -123,8 +131,9 @@ class PPO:
 
     def minibatch_step(self, s0, p0, g, a, old_logp, adv, target_v):
         """One optimiser step on one minibatch (PPO.py:122-147); returns (action_loss, value_loss) tensors."""
-        probs = self.actor(s0, p0, g)
-        value = self.critic(s0, p0, g)
+        x0 = self.policy_input(s0)
+        probs = self.actor(x0, p0, g)
+        value = self.critic(x0, p0, g)
         action_loss, value_loss = ppo_ops.ppo_losses(probs, value, a, old_logp, adv, target_v,
                                                      clip=self.clip_param, ent_coef=self.entropy_coef)
         self.optimizer_actor.zero_grad()
@@ -155,7 +164,7 @@ class PPO:
         r = torch.as_tensor(buffer["r"], dtype=torch.float32, device=device).view(-1)
         old_logp = torch.as_tensor(buffer["a_logp"], dtype=torch.float32, device=device).view(-1, 1)
         n = s.shape[0]
-        self.actor.to(device); self.critic.to(device)
+        self.to(device)
         adv, target_v = self.targets(s, p, g, r)
         if self.normalize_adv:
             ppo_ops.adv_norm_(adv)

@@ -1,0 +1,47 @@
+"""PPO whose actor / critic see the 4 real frames plus 4 frames predicted by a frozen encoder -> LSTM ->
+decoder world model (reference soa/agent/PPO_Predictor.py:72-193).  Only actor and critic train; the
+loss / sampling / advantage math is the same HIP path as PPO (ppo_ops)."""
+import torch
+
+from .net.all_net import (LSTM, Net_Decoder, Net_Encoder, Net_PPO_Predictor_actor, Net_PPO_Predictor_critic)
+from .PPO import PPO
+
+
+class ppo_predictor(PPO):
+    def __init__(self, log_root=None, use_tensorboard=False):
+        super().__init__(log_root=log_root, use_tensorboard=use_tensorboard)
+        # same construction order as the reference (PPO_Predictor.py:32-36)
+        self.actor = Net_PPO_Predictor_actor()
+        self.critic = Net_PPO_Predictor_critic()
+        self.encoder = Net_Encoder()
+        self.decoder = Net_Decoder()
+        self.predictor = LSTM()
+        self.optimizer_actor = torch.optim.Adam(self.actor.parameters(), lr=self.lr, eps=1e-5)
+        self.optimizer_critic = torch.optim.Adam(self.critic.parameters(), lr=self.lr, eps=1e-5)
+        self.scheduler_actor = torch.optim.lr_scheduler.StepLR(self.optimizer_actor, self.lr_step_size, self.lr_gamma)
+        self.scheduler_critic = torch.optim.lr_scheduler.StepLR(self.optimizer_critic, self.lr_step_size, self.lr_gamma)
+
+    def to(self, device):
+        for m in (self.actor, self.critic, self.encoder, self.decoder, self.predictor):
+            m.to(device)
+        return self
+
+    @torch.no_grad()
+    def pred_states(self, state_matrix):
+        """(B,4,289) -> predicted next 4 frames (B,4,289) (+ upsampled inputs, full-res predictions)."""
+        self.encoder.eval(); self.decoder.eval(); self.predictor.eval()
+        z_c, z_up = self.encoder(state_matrix.reshape(-1, 1, 289))
+        z_pred, _ = self.predictor(z_c.view(-1, 4, 64, 4, 4))
+        frames, full = self.decoder(z_pred[:, 3:7])
+        return frames, z_up, full
+
+    def policy_input(self, frames4):
+        """What actor / critic consume: the 4 real frames followed by the 4 predicted ones (8 channels)."""
+        return torch.cat([frames4, self.pred_states(frames4)[0].detach()], dim=1)
+
+    def load_world_model(self, checkpoint):
+        """Checkpoint dict with the reference's keys 'model_encoder', 'model_decoder', 'model_predictor'
+        (train_ppo_predictor.py:81-85)."""
+        self.encoder.load_state_dict(checkpoint["model_encoder"])
+        self.decoder.load_state_dict(checkpoint["model_decoder"])
+        self.predictor.load_state_dict(checkpoint["model_predictor"])

@@ -110,3 +110,72 @@ class Net_PPO_Predictor_actor(Net_PPO_actor):
 
 class Net_PPO_Predictor_critic(Net_PPO_critic):
     in_frames = 8
+
+
+# ---------------------------------------------------------------------------------------------
+# Frozen world-model predictor of the PPO+predictor variant (reference all_net.py:7-137): per-frame
+# encoder -> 3x1024 LSTM rolled 3 steps past its 4 inputs -> per-frame decoder.  Inference only here
+# (PPO_Predictor.py:72-83 runs them under eval() + no_grad); same state_dict keys as the reference.
+class Net_Encoder(nn.Module):
+    """(B,T,289) -> nearest x4 -> conv(1->16,k4,s2)+BN -> conv(16->16,k5,s4)+BN -> conv(16->64,k2,s2)+BN, ReLU each
+    -> latents (B,T,64,4,4) and the upsampled frames (B,T,1,68,68)."""
+
+    def __init__(self):
+        super().__init__()
+        layers = []
+        for cin, cout, k, st in ((1, 16, 4, 2), (16, 16, 5, 4), (16, 64, 2, 2)):
+            layers += [nn.Conv2d(cin, cout, kernel_size=k, stride=st), nn.BatchNorm2d(cout), nn.ReLU()]
+        self.cnn_base = nn.Sequential(*layers)
+        self.apply(reference_init)
+        self.upsamplingnearest = nn.UpsamplingNearest2d(scale_factor=4)
+        self.device = None                          # kept for attribute compatibility; tensors stay where they are
+
+    def forward(self, state_matrix):
+        B, T, _ = state_matrix.shape
+        up = self.upsamplingnearest(state_matrix.reshape(-1, 1, GRID, GRID)).float()
+        z = self.cnn_base(up)
+        return z.view(-1, T, 64, 4, 4), up.view(-1, T, 1, 4 * GRID, 4 * GRID)
+
+
+class LSTM(nn.Module):
+    """3-layer LSTM(1024) over the flattened latents; after the T inputs it is fed its own output
+    nt-4-1 = 3 more times, returning T+3 latents (reference all_net.py:52-98)."""
+
+    def __init__(self):
+        super().__init__()
+        self.extrap_t = 4
+        self.nt = 8
+        self.recurrent_model = nn.LSTM(1024, 1024, num_layers=3, batch_first=True)
+        self.device = None
+
+    def forward(self, z_content):
+        B, T, D, W, H = z_content.shape
+        z_in = z_content.reshape(B, T, D * W * H)
+        zeros = z_in.new_zeros(3, B, 1024)
+        z_past, state = self.recurrent_model(z_in, (zeros, zeros.clone()))
+        z_n = z_past[:, -1:].contiguous()
+        future = []
+        for _ in range(self.nt - 4 - 1):
+            z_n, state = self.recurrent_model(z_n, state)
+            future.append(z_n)
+        z = torch.cat([z_past] + future, dim=1)
+        return z.reshape(B, self.nt - 1, D, W, H), z_in
+
+
+class Net_Decoder(nn.Module):
+    """(B,T,64,4,4) -> convT(64->16,k2,s2) -> convT(16->16,k5,s4) -> convT(16->1,k4,s2) = 68x68 -> AvgPool4 -> (B,T,289)."""
+
+    def __init__(self):
+        super().__init__()
+        self.cnn_base = nn.Sequential(
+            nn.ConvTranspose2d(64, 16, kernel_size=2, stride=2), nn.ReLU(),
+            nn.ConvTranspose2d(16, 16, kernel_size=5, stride=4), nn.ReLU(),
+            nn.ConvTranspose2d(16, 1, kernel_size=4, stride=2))
+        self.apply(reference_init)
+        self.pool = nn.AvgPool2d(4, stride=4)
+
+    def forward(self, z):
+        B, T, D, W, H = z.shape
+        full = self.cnn_base(z.contiguous().view(-1, D, W, H))
+        frames = self.pool(full).view(-1, 1, CELLS).squeeze(-2).reshape(-1, T, CELLS)
+        return frames, full.view(-1, T, 1, 4 * GRID, 4 * GRID)

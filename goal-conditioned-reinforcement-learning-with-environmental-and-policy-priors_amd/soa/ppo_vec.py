@@ -38,7 +38,7 @@ class VecPPOTrainer:
         self.init_frame = self._reset_frame()
         self.frames[:4] = self.init_frame
         self.pos[:4] = self.init_pos
-        agent.actor.to(d); agent.critic.to(d)
+        agent.to(d)
         self.env_steps = 0
         self.episodes_done = 0
         self.return_sum = 0.0
@@ -95,9 +95,9 @@ class VecPPOTrainer:
             t_idx, n_idx = sl // N, sl % N
             g = self.goal1.expand(sl.numel(), 2)
             s0, p0 = self._stacks(t_idx, n_idx, after=False)
-            v[i:i + sl.numel()] = self.agent.critic(s0, p0, g).view(-1)
+            v[i:i + sl.numel()] = self.agent.critic(self.agent.policy_input(s0), p0, g).view(-1)
             s1, p1 = self._stacks(t_idx, n_idx, after=True)
-            nv[i:i + sl.numel()] = self.agent.critic(s1, p1, g).view(-1)
+            nv[i:i + sl.numel()] = self.agent.critic(self.agent.policy_input(s1), p1, g).view(-1)
         done = (self.term | self.trunc).contiguous()
         adv, target, ret = ppo_ops.gae(self.reward, v.view(T, N), nv.view(T, N), done, gamma=self.agent.gamma,
                                        lam=self.agent.gae_lambda, use_done_mask=self.agent.use_done_mask)

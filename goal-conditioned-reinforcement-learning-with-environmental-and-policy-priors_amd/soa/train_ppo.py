@@ -42,10 +42,12 @@ def build_parser():
     p.add_argument("--k_epochs", type=int, default=10)
     p.add_argument("--gae_lambda", type=float, default=0.0)
     p.add_argument("--normalize_adv", action="store_true")
+    p.add_argument("--predictor_file", default=None, help="checkpoint with model_encoder / model_decoder / "
+                   "model_predictor (train_ppo_predictor.py:38,81-85); random-init world model when absent")
     return p
 
 
-def main(argv=None):
+def main(argv=None, predictor=False):
     args = build_parser().parse_args(argv)
     from .. import dist as twdist
     from ..engine import TwoarmyEngine
@@ -60,13 +62,20 @@ def main(argv=None):
     device = torch.device("cuda", local_rank) if world > 1 else torch.device(args.cuda)
     torch.cuda.set_device(device)
 
-    agent = PPO(log_root=args.log_dir)
-    agent.name = "ppo_%s_%sseed_" % (args.env, seed)
+    if predictor:
+        from .agent.PPO_Predictor import ppo_predictor
+        agent = ppo_predictor(log_root=args.log_dir)
+        if args.predictor_file:
+            agent.load_world_model(torch.load(args.predictor_file, map_location="cpu", weights_only=True))
+    else:
+        agent = PPO(log_root=args.log_dir)
+    agent.name = "%s_%s_%sseed_" % ("ppo_predictor" if predictor else "ppo", args.env, seed)
     agent.gamma, agent.K_epochs = args.gamma, args.k_epochs
     agent.gae_lambda, agent.use_done_mask, agent.normalize_adv = args.gae_lambda, args.gae_lambda > 0, args.normalize_adv
     agent.sample_seed = (seed or 0) + 7919 * rank
-    agent.actor.to(device); agent.critic.to(device)
-    twdist.broadcast_parameters([agent.actor, agent.critic])
+    agent.to(device)
+    twdist.broadcast_parameters([agent.actor, agent.critic] +
+                                ([agent.encoder, agent.decoder, agent.predictor] if predictor else []))
     if world > 1:
         agent.grad_sync = twdist.GradBucket(list(agent.actor.parameters()) + list(agent.critic.parameters()))
 

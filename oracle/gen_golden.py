@@ -437,7 +437,73 @@ def gen_her():
     print("her: %d cases -> %s (%.1f KB)" % (len(cases), path_out, os.path.getsize(path_out) / 1024))
 
 
-STAGES = {"traces": gen_traces, "views": gen_views, "ppo": gen_ppo, "her": gen_her}
+# ----------------------------------------------------------------------------- predictor path
+def det_weights_v2(module, seed):
+    """det_weights that also gives BatchNorm sane running statistics (var > 0) and keeps integer buffers."""
+    import torch
+    sd = det_weights(module, seed)
+    for k, (name, prm) in enumerate(module.state_dict().items()):
+        n = prm.numel()
+        if name.endswith("num_batches_tracked"):
+            sd[name] = prm.clone()
+        elif name.endswith("running_var"):
+            sd[name] = torch.tensor(1.0 + 0.3 * np.sin(0.37 * np.arange(n) + k + seed), dtype=prm.dtype)
+        elif name.endswith("running_mean"):
+            sd[name] = torch.tensor(0.1 * np.sin(0.53 * np.arange(n) + k + seed), dtype=prm.dtype)
+        elif ".1.weight" in name or ".4.weight" in name or ".7.weight" in name:
+            if prm.dim() == 1:                      # BatchNorm gamma
+                sd[name] = torch.tensor(1.0 + 0.2 * np.sin(0.41 * np.arange(n) + k + seed), dtype=prm.dtype)
+    return sd
+
+
+def gen_predictor():
+    """soa/agent/PPO_Predictor.py:72-83 pred_states + 8-frame actor/critic with seeded weights
+    (the author's checkpoints are not in the repository)."""
+    import torch
+    env_buffer, ppo_mod = rh.soa_modules()
+    from agent import PPO_Predictor as pp_mod
+    pp_mod.heatmap = lambda *a, **k: None
+    out = {}
+    torch.manual_seed(SEED)
+    agent = pp_mod.ppo_predictor()
+    for tag, net in (("actor", agent.actor), ("critic", agent.critic), ("encoder", agent.encoder),
+                     ("decoder", agent.decoder)):
+        st = param_stats(net)
+        out["init_%s_names" % tag] = np.array([x[0] for x in st])
+        out["init_%s_sum" % tag] = np.array([x[2] for x in st])
+        out["init_%s_abs" % tag] = np.array([x[3] for x in st])
+    out["init_predictor_names"] = np.array(list(agent.predictor.state_dict().keys()))
+    out["init_predictor_sum"] = np.array([float(v.double().sum()) for v in agent.predictor.state_dict().values()])
+    for i, net in enumerate((agent.actor, agent.critic, agent.encoder, agent.decoder)):
+        net.load_state_dict(det_weights_v2(net, 11 + i))
+    lstm_sd = {}
+    for k, (name, prm) in enumerate(agent.predictor.state_dict().items()):
+        n = prm.numel()
+        lstm_sd[name] = torch.tensor((0.03 * np.sin(0.37 * np.arange(n, dtype=np.float64) + 1.3 * k)).reshape(tuple(prm.shape)),
+                                     dtype=prm.dtype)
+    agent.predictor.load_state_dict(lstm_sd)
+    dev = torch.device("cpu")
+    agent.encoder.device = agent.predictor.device = dev
+    buf = collect_buffer(env_buffer, "v4", 64, seed=4)
+    b = buf.buffer
+    s = torch.tensor(b['s'][[5, 20, 41]][:, 1:5])
+    pp = torch.tensor(b['p'][[5, 20, 41]][:, 1:5]); g = torch.tensor(b['g'][[5, 20, 41]])
+    heads, up, full = agent.pred_states(s)
+    cat = torch.cat([s, heads.detach()], 1)
+    agent.actor.eval(); agent.critic.eval()
+    with torch.no_grad():
+        out["probs"] = agent.actor(cat, pp, g).numpy()
+        out["value"] = agent.critic(cat, pp, g).numpy()
+    out["in_s"] = s.numpy(); out["in_p"] = pp.numpy(); out["in_g"] = g.numpy()
+    out["pred_frames"] = heads.numpy()
+    out["pred_full_sum"] = full.double().sum(dim=(2, 3, 4)).numpy()
+    path_out = os.path.join(GOLD, "predictor.npz")
+    np.savez_compressed(path_out, **out)
+    print("predictor: pred_frames range [%.4f, %.4f] -> %s (%.1f KB)" % (heads.min(), heads.max(), path_out,
+                                                                         os.path.getsize(path_out) / 1024))
+
+
+STAGES = {"traces": gen_traces, "views": gen_views, "ppo": gen_ppo, "her": gen_her, "predictor": gen_predictor}
 
 
 def main(argv):

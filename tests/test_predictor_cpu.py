@@ -1,0 +1,68 @@
+"""Predictor path (frozen encoder -> LSTM -> decoder + 8-frame actor/critic) vs outputs recorded from the
+reference's own modules with seeded weights (tests/golden/predictor.npz).  Pure torch: runs on CPU."""
+import numpy as np
+import torch
+
+from test_ppo_common import GOLDEN, det_weights
+
+
+def det_weights_v2(module, seed):
+    sd = det_weights(module, seed)
+    for k, (name, prm) in enumerate(module.state_dict().items()):
+        n = prm.numel()
+        if name.endswith("num_batches_tracked"):
+            sd[name] = prm.clone()
+        elif name.endswith("running_var"):
+            sd[name] = torch.tensor(1.0 + 0.3 * np.sin(0.37 * np.arange(n) + k + seed), dtype=prm.dtype)
+        elif name.endswith("running_mean"):
+            sd[name] = torch.tensor(0.1 * np.sin(0.53 * np.arange(n) + k + seed), dtype=prm.dtype)
+        elif (".1.weight" in name or ".4.weight" in name or ".7.weight" in name) and prm.dim() == 1:
+            sd[name] = torch.tensor(1.0 + 0.2 * np.sin(0.41 * np.arange(n) + k + seed), dtype=prm.dtype)
+    return sd
+
+
+def _agent():
+    from twoarmy_amd.soa.agent.PPO_Predictor import ppo_predictor
+    return ppo_predictor
+
+
+def test_init_and_keys_match_reference_under_seed():
+    g = dict(np.load(GOLDEN + "/predictor.npz"))
+    torch.manual_seed(9981)
+    from twoarmy_amd.soa.agent.net.all_net import (LSTM, Net_Decoder, Net_Encoder, Net_PPO_Predictor_actor,
+                                                   Net_PPO_Predictor_critic)
+    nets = dict(actor=Net_PPO_Predictor_actor(), critic=Net_PPO_Predictor_critic(), encoder=Net_Encoder(),
+                decoder=Net_Decoder())
+    lstm = LSTM()
+    for tag, net in nets.items():
+        sd = net.state_dict()
+        assert list(sd.keys()) == [str(x) for x in g["init_%s_names" % tag]], tag
+        sums = np.array([float(v.double().sum()) for v in sd.values()])
+        abss = np.array([float(v.double().abs().sum()) for v in sd.values()])
+        assert np.array_equal(sums, g["init_%s_sum" % tag]) and np.array_equal(abss, g["init_%s_abs" % tag]), tag
+    assert list(lstm.state_dict().keys()) == [str(x) for x in g["init_predictor_names"]]
+    assert np.array_equal(np.array([float(v.double().sum()) for v in lstm.state_dict().values()]),
+                          g["init_predictor_sum"])
+
+
+def test_pred_states_and_heads_match_reference():
+    g = dict(np.load(GOLDEN + "/predictor.npz"))
+    agent = _agent()()
+    for i, net in enumerate((agent.actor, agent.critic, agent.encoder, agent.decoder)):
+        net.load_state_dict(det_weights_v2(net, 11 + i))
+    sd = {}
+    for k, (name, prm) in enumerate(agent.predictor.state_dict().items()):
+        n = prm.numel()
+        sd[name] = torch.tensor((0.03 * np.sin(0.37 * np.arange(n, dtype=np.float64) + 1.3 * k)).reshape(tuple(prm.shape)),
+                                dtype=prm.dtype)
+    agent.predictor.load_state_dict(sd)
+    s, p, goal = (torch.tensor(g[k]) for k in ("in_s", "in_p", "in_g"))
+    frames, up, full = agent.pred_states(s)
+    np.testing.assert_allclose(frames.numpy(), g["pred_frames"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(full.double().sum(dim=(2, 3, 4)).numpy(), g["pred_full_sum"], rtol=1e-5, atol=1e-4)
+    x = agent.policy_input(s)
+    assert x.shape == (3, 8, 289) and torch.equal(x[:, :4], s)
+    agent.actor.eval(); agent.critic.eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(agent.actor(x, p, goal).numpy(), g["probs"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(agent.critic(x, p, goal).numpy(), g["value"], rtol=1e-5, atol=1e-5)

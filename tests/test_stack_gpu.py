@@ -110,3 +110,10 @@ def test_train_ppo_entry_point_smoke():
     tr = train_ppo.main(["--env", "MiniGrid-twoarmy-17x17-v4", "--num_envs", "64", "--rollout_steps", "16",
                          "--minibatch", "256", "--updates", "2", "--k_epochs", "1", "--cuda", "cuda:0"])
     assert tr.env_steps == 2 * 16 * 64
+
+
+def test_train_ppo_predictor_entry_point_smoke():
+    from twoarmy_amd.soa import train_ppo_predictor
+    tr = train_ppo_predictor.main(["--env", "MiniGrid-twoarmy-17x17-v4", "--num_envs", "32", "--rollout_steps", "8",
+                                   "--minibatch", "128", "--updates", "1", "--k_epochs", "1", "--cuda", "cuda:0"])
+    assert tr.env_steps == 8 * 32 and tr.agent.actor.bone1.cnn_base[0].weight.shape[1] == 8
