@@ -46,18 +46,16 @@ def traffic_from_profile(variant, n_envs, rollout_t, view):
         return json.load(f)["traffic_bytes_per_launch"]
 
 
-def cpu_baseline(variant, n_envs, view):
-    """CPU oracle ("port": oracle/twoarmy_oracle.c, single thread) on a bounded sample of the same workload."""
+def cpu_baseline(variant, n_envs, view, seconds=12.0):
+    """CPU oracle ("port": oracle/twoarmy_oracle.c, single thread) on a bounded sample of the same workload:
+    the same 4096 envs stepped with the same Philox action stream and auto-reset for ~12 s of CPU time."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import twoarmy_oracle as orc
     orc.lib()
-    t_sample = 256
-    t0 = time.perf_counter()
-    orc.rollout(variant, n_envs, t_sample, SEED, view=view)
-    dt = time.perf_counter() - t0
-    return {"value": n_envs * t_sample / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+    steps, dt = orc.timed_rollout(variant, n_envs, seconds, SEED, view=view)
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
             "sample": "%d envs x %d steps of the same workload (oracle/twoarmy_oracle.c, gcc -O2, 1 thread, %.1f s)"
-                      % (n_envs, t_sample, dt),
+                      % (n_envs, steps // n_envs, dt),
             "host_cores_available": os.cpu_count()}
 
 

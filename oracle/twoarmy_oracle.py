@@ -118,6 +118,30 @@ class OracleEnv:
                     ball_x=tuple(e.ob_x), ball_y=tuple(e.ob_y))
 
 
+def timed_rollout(variant, N, seconds, seed, view=17, chunk=64):
+    """CPU baseline leg of bench.py: keep stepping the same N envs (state carried across chunks, outputs
+    written to reused [chunk,N,...] buffers) for about `seconds`; returns (env_steps, elapsed_seconds)."""
+    import time
+    envs = (TwEnv * N)()
+    for n in range(N):
+        lib().tw_oracle_init(C.byref(envs[n]), variant)
+    obs = np.empty((chunk, N, view, view, 3), np.uint8)
+    mat = np.empty((chunk, N, NC), np.float32)
+    pos = np.empty((chunk, N, 2), np.float32)
+    rew = np.empty((chunk, N), np.float32)
+    te = np.empty((chunk, N), np.uint8)
+    tr = np.empty((chunk, N), np.uint8)
+    steps = 0
+    t0 = time.perf_counter()
+    while True:
+        lib().tw_oracle_rollout(variant, N, chunk, seed, 0, view, None, C.cast(envs, C.c_void_p), _ptr(obs), _ptr(mat),
+                                _ptr(pos), _ptr(rew), _ptr(te), _ptr(tr), 1)
+        steps += N * chunk
+        dt = time.perf_counter() - t0
+        if dt >= seconds:
+            return steps, dt
+
+
 def rollout(variant, N, T, seed, env0=0, view=17, actions=None, autoreset=True,
             want_obs=True, want_matrix=True):
     """Batched CPU rollout; returns dict of [T,N,...] arrays."""
