@@ -21,7 +21,7 @@ TW_F_POLICY_IDX = 2
 FIELDS = dict(AX=0, AY=1, DIR=2, STEP_COUNT=3, STEP_MOVE=4, PONE=5, PATROL=6, UP1=7, RIGHT2=8, UPD_LONG=9,
               UPD_HORIZ=10, RISK=11, FIRST_ROOM2=12, OBX=13, OBY=16, O1X=19, O1Y=22, O1_VALID=25, O2X=26,
               O2Y=30, O2_VALID=34, GOAL_X=35, GOAL_Y=36, T=37, ERROR=38, MAX_STEPS=39, EPISODES=40,
-              LAST_REWARD=41, LAST_TERM=42, LAST_TRUNC=43)
+              LAST_REWARD=41, LAST_TERM=42, LAST_TRUNC=43, WALL_I1=44, WALL_I2=45)
 
 ENV_ERRORS = {1: AttributeError, 2: AssertionError, 3: TypeError}
 
@@ -46,6 +46,7 @@ _SIGS = {
     "tw_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "tw_rollout": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "tw_set_envs_per_wave": (C.c_int, [_vp, C.c_int]),
+    "tw_set_pipeline": (C.c_int, [_vp, C.c_int]),
     "tw_fill_actions": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "tw_state_ptrs": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "tw_get_state_host": (C.c_int, [_vp, _vp, _vp, _vp]),

@@ -65,9 +65,14 @@ constexpr int STAGE_WORDS = 220;
 enum { R_STEP = 0, R_RISK = 1, R_HIT = 2, R_ROOM2 = 3, R_GOAL = 4 };
 
 struct Params {
-    uint8_t *type;
+    uint8_t *type;            // state read from here ...
     uint8_t *colour;
     int32_t *rec;
+    uint8_t *type_out;        // ... and written here (== the inputs for an in-place launch)
+    uint8_t *colour_out;
+    int32_t *rec_out;
+    int *abnormal;            // device flag raised by the pipelined kernel when an env leaves normal play
+    int only_if_flagged;      // sequential kernel: run only if *abnormal != 0 (fallback launch)
     int n_envs;
     int view;
     int variant;
@@ -132,6 +137,7 @@ struct EnvS {
     int obx[3], oby[3], o1x[3], o1y[3], o1v, o2x[4], o2y[4], o2v, gx, gy;
     uint32_t t;
     int err, max_steps, episodes, last_reward, last_term, last_trunc;
+    int wall_i1, wall_i2;     // offsets of the two dropped 2x2 wall blocks (valid while pone)
 };
 
 __device__ __forceinline__ void load_env(EnvS &s, const int32_t *r) {
@@ -153,6 +159,7 @@ __device__ __forceinline__ void load_env(EnvS &s, const int32_t *r) {
     s.t = (uint32_t)r[TW_T]; s.err = r[TW_ERROR]; s.max_steps = r[TW_MAX_STEPS];
     s.episodes = r[TW_EPISODES]; s.last_reward = r[TW_LAST_REWARD];
     s.last_term = r[TW_LAST_TERM]; s.last_trunc = r[TW_LAST_TRUNC];
+    s.wall_i1 = r[TW_WALL_I1]; s.wall_i2 = r[TW_WALL_I2];
 }
 
 __device__ __forceinline__ void store_env(const EnvS &s, int32_t *r) {
@@ -173,6 +180,7 @@ __device__ __forceinline__ void store_env(const EnvS &s, int32_t *r) {
     r[TW_T] = (int32_t)s.t; r[TW_ERROR] = s.err; r[TW_MAX_STEPS] = s.max_steps;
     r[TW_EPISODES] = s.episodes; r[TW_LAST_REWARD] = s.last_reward;
     r[TW_LAST_TERM] = s.last_term; r[TW_LAST_TRUNC] = s.last_trunc;
+    r[TW_WALL_I1] = s.wall_i1; r[TW_WALL_I2] = s.wall_i2;
 }
 
 // MiniGridEnv.reset + _gen_grid on the scalar side (minigrid.py:947-980, twoarmy_v6.py:56-77).
@@ -405,6 +413,7 @@ __global__ __launch_bounds__(64, (E == 1 ? 4 : 2)) void tw_rollout_kernel(Params
     __shared__ int32_t act_lds[64 * E];
 
     constexpr bool V4 = VARIANT == 4;
+    if (p.only_if_flagged && *p.abnormal == 0) return;   // fallback launch behind the pipelined kernel
     const int lane = threadIdx.x;
     const int N = p.n_envs;
     const int n0 = blockIdx.x * E;                      // first env of this wave
@@ -699,7 +708,7 @@ __global__ __launch_bounds__(64, (E == 1 ? 4 : 2)) void tw_rollout_kernel(Params
                     put(my_env, 4, i1 + 1, C_WALL, M_WALL); put(my_env, 5, i1 + 1, C_WALL, M_WALL);
                     put(my_env, i2, 11, C_WALL, M_WALL); put(my_env, i2, 12, C_WALL, M_WALL);
                     put(my_env, i2 + 1, 11, C_WALL, M_WALL); put(my_env, i2 + 1, 12, C_WALL, M_WALL);
-                    s.pone = 1;
+                    s.pone = 1; s.wall_i1 = i1; s.wall_i2 = i2;
                 }
                 if (V4 && !s.patrol && s.ay <= 8) {               // twoarmy_v4.py:212-225
                     const int i = 6 + (int)(dw[TW_S_SPAWN] % 4u);
@@ -896,7 +905,7 @@ __global__ __launch_bounds__(64, (E == 1 ? 4 : 2)) void tw_rollout_kernel(Params
     wave_sync();
     for (int i = lane; i < E * REC; i += 64) {
         const int e = i / REC;
-        if (n0 + e < N) p.rec[(size_t)n0 * REC + i] = recs[i];
+        if (n0 + e < N) p.rec_out[(size_t)n0 * REC + i] = recs[i];
     }
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -906,8 +915,421 @@ __global__ __launch_bounds__(64, (E == 1 ? 4 : 2)) void tw_rollout_kernel(Params
         for (int c = lane; c < NC; c += 64) {
             const int y = c / GS, x = c - y * GS;
             const uint32_t v = env[gpi(x, y)];
-            p.type[gb + c] = (uint8_t)v;
-            p.colour[gb + c] = (uint8_t)(v >> 8);
+            p.type_out[gb + c] = (uint8_t)v;
+            p.colour_out[gb + c] = (uint8_t)(v >> 8);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- the pipelined rollout kernel
+// Normal play only (auto-reset on, Philox draws, native layouts, facing up): in that regime the grid is
+// a closed-form function of seven small integers,
+//     static map + ball triple at b0 + [pone: two 2x2 wall blocks at i1 / i2]
+//                + [patrol: column of 3 balls at (12, o1y0..) and 2x2 balls at (o2x0.., 4..5)],
+// so the sequential part of a step (the transition) and the heavy part (emitting 2 KB of observation +
+// state matrix) can be decoupled.  One workgroup = 16 waves owns 16 envs:
+//   * wave 0 (LOGIC): lanes 0..15 run the transition analytically -- no LDS grid -- and publish one packed
+//     32-bit record per env-step into an LDS ring, plus reward / terminated / truncated / pos to HBM;
+//   * all waves (EMIT, wave 0 joins when its chunk is done) pull (step, env) tasks from an LDS counter,
+//     patch <= 18 dynamic cells into their private copy of the static wall-padded grid + matrix image,
+//     emit with the same register-packed paths as the sequential kernel, and un-patch.
+// Emission of different steps is independent, so the 15 emit waves hide each other's latencies and the
+// kernel runs at the HBM write rate instead of at one wave's dependent-instruction latency.
+// Anything outside normal play (illegal action, drifted balls, injected grids, ...) raises *p.abnormal;
+// the host always enqueues the sequential kernel behind this one, which re-runs the launch from the
+// untouched input state iff the flag is set (both write the `_out` state; the host swaps afterwards).
+constexpr int PG = 16;          // envs per workgroup
+constexpr int PWAVES = 16;      // waves per workgroup
+constexpr int PCH = 128;        // steps per ring chunk
+constexpr uint32_t REC_VALID = 0x80000000u;
+
+struct Dyn { int b0, pone, i1, i2, patrol, o1y0, o2x0; };
+
+__device__ __forceinline__ uint32_t static_cell(int x, int y) {      // _gen_grid without the balls
+    if (x == 0 || y == 0 || x == GS - 1 || y == GS - 1) return C_WALL;
+    if (y == 8) return (x <= 5 || x >= 11) ? C_WALL : C_EMPTY;
+    if (x == 14 && y == 2) return C_GOAL;
+    return C_EMPTY;
+}
+
+__device__ __forceinline__ uint32_t analytic_cell(int x, int y, const Dyn &d) {
+    uint32_t c = static_cell(x, y);
+    if (y == 8 && (unsigned)(x - d.b0) <= 2u) c = C_BALL;
+    if (d.pone && ((((unsigned)(x - 4) <= 1u) & ((unsigned)(y - d.i1) <= 1u)) |
+                   (((unsigned)(x - d.i2) <= 1u) & ((unsigned)(y - 11) <= 1u)))) c = C_WALL;
+    if (d.patrol && (((x == 12) & ((unsigned)(y - d.o1y0) <= 2u)) |
+                     (((unsigned)(x - d.o2x0) <= 1u) & ((unsigned)(y - 4) <= 1u)))) c = C_BALL;
+    return c;
+}
+
+// is the scalar state inside the closed-form regime?  (the planes are checked against analytic_cell separately)
+template <bool V4>
+__device__ __forceinline__ bool pipe_state_ok(const EnvS &s) {
+    bool ok = normal_mode(s) & ((unsigned)(s.obx[0] - 6) <= 2u) & (s.err == 0) & (s.gx == 14) & (s.gy == 2) &
+              (s.max_steps > 0);
+    if (s.pone) ok &= ((unsigned)(s.wall_i1 - 9) <= 3u) & ((unsigned)(s.wall_i2 - 6) <= 3u);
+    if (V4) {
+        if (s.patrol) {
+            ok &= (s.o1v != 0) & (s.o2v != 0) & (s.o1x[0] == 12) & (s.o1x[1] == 12) & (s.o1x[2] == 12) &
+                  (s.o1y[1] == s.o1y[0] + 1) & (s.o1y[2] == s.o1y[0] + 2) & ((unsigned)(s.o1y[0] - 3) <= 2u) &
+                  ((unsigned)(s.o2x[0] - 5) <= 5u) & (s.o2x[1] == s.o2x[0] + 1) & (s.o2x[2] == s.o2x[0]) &
+                  (s.o2x[3] == s.o2x[0] + 1) & (s.o2y[0] == 4) & (s.o2y[1] == 4) & (s.o2y[2] == 5) & (s.o2y[3] == 5);
+        }
+    } else {
+        ok &= (s.patrol == 0);
+    }
+    return ok;
+}
+
+__device__ __forceinline__ uint32_t pack_record(int ax, int ay, const Dyn &d, int pone_pre, int patrol_pre) {
+    return (uint32_t)ax | ((uint32_t)ay << 5) | ((uint32_t)d.b0 << 10) | ((uint32_t)(d.o1y0 & 7) << 14) |
+           ((uint32_t)(d.o2x0 & 15) << 17) | ((uint32_t)((d.i1 - 9) & 3) << 21) | ((uint32_t)((d.i2 - 6) & 3) << 23) |
+           ((uint32_t)pone_pre << 25) | ((uint32_t)d.pone << 26) | ((uint32_t)patrol_pre << 27) |
+           ((uint32_t)d.patrol << 28);
+}
+
+template <int VARIANT>
+__global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t pipe_lds[];
+    uint32_t *img = pipe_lds;                                   // [PWAVES][ENV_WORDS]
+    uint32_t *ring = img + PWAVES * ENV_WORDS;                  // [PCH][PG]
+    int32_t *recs = reinterpret_cast<int32_t *>(ring + PCH * PG);   // [PG][REC]
+    volatile int *ctrl = reinterpret_cast<volatile int *>(recs + PG * REC);   // [0] ready  [1] next task
+    int32_t *acts = const_cast<int32_t *>(reinterpret_cast<volatile int32_t *>(ctrl + 4));   // [PCH][PG] actions of the chunk
+
+    constexpr bool V4 = VARIANT == 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = p.n_envs, V = p.view;
+    const int n0 = blockIdx.x * PG;
+    uint32_t *my_img = img + wave * ENV_WORDS;
+
+    // ---- private static image per wave; records of the block's envs
+    for (int i = lane; i < GP_WORDS; i += 64) {
+        const int y = i / GPW - GPY0, x = i - (i / GPW) * GPW - GPX0;
+        my_img[i] = inb(x, y) ? static_cell(x, y) : C_WALL;
+    }
+    for (int c = lane; c < MAT_WORDS; c += 64)
+        my_img[MAT_OFF + c] = c < NC ? mat_of_code(static_cell(c - (c / GS) * GS, c / GS)) : 0u;
+    if (lane < REC) recs[wave * REC + lane] = (n0 + wave < N) ? p.rec[(size_t)(n0 + wave) * REC + lane] : 0;
+    if (tid == 0) { ctrl[0] = 0; ctrl[1] = 0; }
+    __syncthreads();
+
+    // ---- wave e verifies env n0+e: scalar regime + planes == closed form
+    {
+        EnvS s;
+        load_env(s, recs + wave * REC);
+        bool ok = true;
+        if (n0 + wave < N) {
+            ok = pipe_state_ok<V4>(s);
+            Dyn d = {s.obx[0], s.pone, s.wall_i1, s.wall_i2, s.patrol, s.o1y[0], s.o2x[0]};
+            const size_t gb = (size_t)(n0 + wave) * NC;
+            for (int c = lane; c < NC; c += 64) {
+                const uint32_t want = analytic_cell(c - (c / GS) * GS, c / GS, d);
+                const uint32_t have = (uint32_t)p.type[gb + c] | ((uint32_t)p.colour[gb + c] << 8);
+                ok &= (want == have);
+            }
+        }
+        if (__ballot(!ok) != 0ull && lane == 0) atomicOr(p.abnormal, 1);
+    }
+    __syncthreads();
+
+    // ---- emission constants of this lane
+    const ObsFast of = make_obs_fast(lane, V);
+    // dynamic-cell slot of this lane: 0-2 balls, 3-10 wall blocks, 11-13 patrol column, 14-17 patrol square
+    int dc_xc = 0, dc_yc = 0, dc_xs = 0, dc_ys = 0, dc_grp = 3;
+    uint32_t dc_code = C_BALL, dc_mval = M_BALL;
+    if (lane < 3) { dc_grp = 0; dc_xs = 1; dc_xc = lane; dc_yc = 8; }
+    else if (lane < 7) { const int k = lane - 3; dc_grp = 1; dc_xc = 4 + (k & 1); dc_ys = 1; dc_yc = k >> 1; dc_code = C_WALL; dc_mval = M_WALL; }
+    else if (lane < 11) { const int k = lane - 7; dc_grp = 1; dc_xs = 2; dc_xc = k >> 1; dc_yc = 11 + (k & 1); dc_code = C_WALL; dc_mval = M_WALL; }
+    else if (lane < 14) { dc_grp = 2; dc_xc = 12; dc_ys = 2; dc_yc = lane - 11; }
+    else if (lane < 18) { const int k = lane - 14; dc_grp = 2; dc_xs = 3; dc_xc = k & 1; dc_yc = 4 + (k >> 1); }
+
+    // ---- LOGIC state of wave 0 (lane e <-> env n0+e): only the fields the closed-form transition touches
+    //      (everything else stays in the LDS copy of the record and is written back unchanged)
+    const bool lg_active = wave == 0 && lane < PG && n0 + lane < N;
+    struct {
+        int ax, ay, step_count, step_move, m6, m4, up1, right2, upd_long, upd_horiz, risk, first_room2, max_steps,
+            episodes, last_reward, last_term, last_trunc;
+        uint32_t t;
+    } s;
+    Dyn d;
+    {
+        const int32_t *r = recs + (lane < PG ? lane : 0) * REC;
+        s.ax = r[TW_AX]; s.ay = r[TW_AY]; s.step_count = r[TW_STEP_COUNT]; s.step_move = r[TW_STEP_MOVE];
+        s.m6 = (int)((uint32_t)s.step_move % 6u); s.m4 = s.step_move & 3;
+        s.up1 = r[TW_UP1]; s.right2 = r[TW_RIGHT2]; s.upd_long = r[TW_UPD_LONG]; s.upd_horiz = r[TW_UPD_HORIZ];
+        s.risk = r[TW_RISK]; s.first_room2 = r[TW_FIRST_ROOM2]; s.max_steps = r[TW_MAX_STEPS];
+        s.episodes = r[TW_EPISODES]; s.last_reward = r[TW_LAST_REWARD]; s.last_term = r[TW_LAST_TERM];
+        s.last_trunc = r[TW_LAST_TRUNC]; s.t = (uint32_t)r[TW_T];
+        d.b0 = r[TW_OBX]; d.pone = r[TW_PONE]; d.i1 = r[TW_WALL_I1]; d.i2 = r[TW_WALL_I2]; d.patrol = r[TW_PATROL];
+        d.o1y0 = r[TW_O1Y]; d.o2x0 = r[TW_O2X];
+    }
+    const uint32_t env_id = p.env_id0 + (uint32_t)(n0 + lane);
+    const bool policy_idx = (p.flags & TW_F_POLICY_IDX) != 0;
+    bool bad = false;
+
+    for (int c0 = 0; c0 < p.T; c0 += PCH) {
+        const int len = min(PCH, p.T - c0);
+        // the chunk's actions go to LDS up front: the logic wave must never wait on vmcnt (on gfx950 a load
+        // retires behind every older store, and the emit waves keep the write queues full)
+        for (int i = tid; i < len * PG; i += 64 * PWAVES) {
+            const int tl = i / PG, e = i - tl * PG;
+            acts[i] = (n0 + e < N) ? p.actions[(size_t)(c0 + tl) * N + n0 + e] : 0;
+            ring[i] = 0u;
+        }
+        __syncthreads();
+#ifdef TW_STAMP
+        unsigned long long pst_l = 0, pst_poll = 0, pst_work = 0, pst_tasks = 0, pst_t0 = 0, pst_t1 = 0;
+#define PSTAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory")
+#else
+#define PSTAMP(v) do { } while (0)
+#endif
+        if (wave == 0) {
+            // ================= LOGIC: the transition in closed form, one step per iteration
+            PSTAMP(pst_t0);
+            __builtin_amdgcn_s_setprio(3);        // the serial chain must win issue arbitration on its SIMD
+            for (int tl = 0; tl < len; ++tl) {
+                const int tt = c0 + tl;
+                if (lg_active) {
+                    const size_t idx = (size_t)tt * N + n0 + lane;
+                    int action = acts[tl * PG + lane];
+                    if (policy_idx && action == 4) action = 6;
+                    if (action >= 7) action = 0;
+                    bad |= !(((unsigned)action <= 6u) & (((0x4Fu >> (action & 7)) & 1u) != 0u));
+                    action = min(max(action, 0), 6);
+                    const uint32_t t_now = s.t;
+                    uint32_t dw[4] = {0, 0, 0, 0};
+                    if (V4) draw_block(p.seed_lo, p.seed_hi, env_id, t_now, 0, dw);
+                    s.t += 1;
+                    s.step_move += 1;
+                    s.m6 = s.m6 == 5 ? 0 : s.m6 + 1;
+                    s.m4 = (s.m4 + 1) & 3;
+                    const int m6 = s.m6;
+                    d.b0 += (m6 <= 1) ? 1 : (m6 <= 3 ? -1 : 0);          // twoarmy_v6.py:96-112
+                    bad |= (unsigned)(d.b0 - 6) > 2u;
+                    d.b0 = min(max(d.b0, 6), 8);
+                    if (V4) {                                             // twoarmy_v4.py:115-176
+                        if (s.upd_long) {
+                            s.upd_horiz = 0;
+                            bool go = (s.m4 == 2) | (m6 == 3) | (m6 == 0);
+                            go |= (dw[TW_S_GATE] % 10u) == 6u;
+                            if (go && d.patrol) {
+                                d.o1y0 += s.up1 ? -1 : 1;
+                                if (s.up1) { if (d.o1y0 == 3) s.up1 = 0; } else { if (d.o1y0 + 2 == 7) s.up1 = 1; }
+                            }
+                        }
+                        if (s.upd_horiz) {
+                            s.upd_long = 0;
+                            bool go = (m6 != 1);
+                            go |= (dw[TW_S_GATE] % 10u) == 6u;
+                            if (go && d.patrol) {
+                                d.o2x0 += s.right2 ? 1 : -1;
+                                if (s.right2) { if (d.o2x0 + 1 == 11) s.right2 = 0; } else { if (d.o2x0 == 5) s.right2 = 1; }
+                            }
+                        }
+                        bad |= d.patrol && (((unsigned)(d.o1y0 - 3) > 2u) | ((unsigned)(d.o2x0 - 5) > 5u));
+                        d.o1y0 = min(max(d.o1y0, 3), 5); d.o2x0 = min(max(d.o2x0, 5), 10);
+                    }
+                    // MiniGridEnv.step (minigrid.py:1333-1441) against the closed-form grid
+                    s.step_count += 1;
+                    const int tx = s.ax + (int)((0x1558u >> (2 * action)) & 3u) - 1;
+                    const int ty = s.ay + (int)((0x1585u >> (2 * action)) & 3u) - 1;
+                    const uint32_t ct = analytic_cell(tx, ty, d) & 0xffu;
+                    const bool enter = (ct == 1u) | (ct == 8u);
+                    s.ax = enter ? tx : s.ax;
+                    s.ay = enter ? ty : s.ay;
+                    int terminated = ct == 8u;
+                    int truncated = s.step_count >= s.max_steps;
+                    bad |= ((unsigned)(s.ax - 1) > 14u) | ((unsigned)(s.ay - 1) > 14u);
+                    const int pone_pre = d.pone, patrol_pre = d.patrol;
+                    // ---- after gen_obs(): wall drop, patrol spawn (twoarmy_v6.py:182-198, v4:181-225)
+                    if (!d.pone && (s.ax > 3 || s.ay < 14)) {
+                        d.i1 = V4 ? 9 + (int)(dw[TW_S_WALL1] % 4u) : 11;
+                        d.i2 = V4 ? 6 + (int)(dw[TW_S_WALL2] % 4u) : 8;
+                        d.pone = 1;
+                    }
+                    if (V4 && !d.patrol && s.ay <= 8) {
+                        d.o2x0 = 6 + (int)(dw[TW_S_SPAWN] % 4u);
+                        d.o1y0 = 4;
+                        d.patrol = 1;
+                    }
+                    // shaped reward (twoarmy_v6.py:231-294)
+                    int reward = R_STEP;
+                    const bool in_span = (unsigned)(s.ax - d.b0) <= 2u;
+                    bool hit = in_span & (s.ay == 8);
+                    reward = hit ? R_HIT : reward;
+                    reward = (in_span & (s.ay == 9)) ? R_RISK : reward;
+                    if (V4 && d.patrol) {
+                        const bool sq_rows = (unsigned)(s.ay - 4) <= 1u, col_rows = (unsigned)(s.ay - d.o1y0) <= 2u;
+                        const bool prisk = ((s.ay == 6) & ((unsigned)(s.ax - d.o2x0) <= 1u)) | ((s.ax == d.o2x0 - 1) & sq_rows) |
+                                           ((s.ax == d.o2x0 + 2) & sq_rows) | ((s.ax == 11) & col_rows);
+                        const bool phit = ((s.ax == 12) & col_rows) | (((unsigned)(s.ax - d.o2x0) <= 1u) & sq_rows);
+                        reward = prisk ? R_RISK : reward;
+                        reward = phit ? R_HIT : reward;
+                        hit |= phit;
+                    }
+                    truncated |= hit;
+                    const bool room2 = s.first_room2 & (s.ay == 7);
+                    reward = room2 ? R_ROOM2 : reward;
+                    s.first_room2 = room2 ? 0 : s.first_room2;
+                    s.risk += (reward == R_RISK);
+                    truncated |= (reward == R_RISK) & (s.risk > 5);
+                    const uint32_t record = pack_record(s.ax, s.ay, d, pone_pre, patrol_pre);
+                    const float2 ps = make_float2((float)s.ay, (float)s.ax);
+                    if (terminated || truncated) {                        // twoarmy_v6.py:296-318 + auto-reset
+                        if (terminated) reward = R_GOAL;
+                        s.step_move = 0; s.m6 = 0; s.m4 = 0; s.first_room2 = 1; s.risk = 0;
+                        uint32_t cw[4];
+                        draw_block(p.seed_lo, p.seed_hi, env_id, t_now, 1, cw);
+                        if ((cw[0] & 1u) == 1u) { s.up1 = 0; s.right2 = 1; } else { s.up1 = 1; s.right2 = 0; }
+                        if ((cw[1] & 1u) == 1u) { s.upd_horiz = 0; s.upd_long = 1; } else { s.upd_horiz = 1; s.upd_long = 0; }
+                        s.episodes += 1;
+                        d.pone = 0; d.patrol = 0; d.b0 = 7;
+                        s.ax = 3; s.ay = 15; s.step_count = 0;
+                    }
+                    s.last_reward = reward; s.last_term = terminated; s.last_trunc = truncated;
+                    ring[tl * PG + lane] = record | REC_VALID;      // single-word publish: valid bit + payload together
+                    p.reward[idx] = reward_value(reward);
+                    p.term[idx] = (uint8_t)terminated;
+                    p.trunc[idx] = (uint8_t)truncated;
+                    reinterpret_cast<float2 *>(p.pos)[idx] = ps;
+                }
+                else if (lane < PG) ring[tl * PG + lane] = REC_VALID;   // padding env of a ragged last block
+            }
+            if (__ballot(bad) != 0ull && lane == 0) atomicOr(p.abnormal, 1);
+            __builtin_amdgcn_s_setprio(0);
+            PSTAMP(pst_t1);
+#ifdef TW_STAMP
+            pst_l = pst_t1 - pst_t0;
+            if (lane == 0 && blockIdx.x < 64) g_stamp[blockIdx.x][0] = pst_l;
+#endif
+        }
+        // ================= EMIT: pull groups of 8 (step, env) tasks
+        const int ngroups = len * (PG / 8);
+        while (true) {
+            int kg = 0;
+            if (lane == 0) kg = atomicAdd(const_cast<int *>(&ctrl[1]), 1);
+            kg = __builtin_amdgcn_readfirstlane(kg);
+            if (kg >= ngroups) break;
+            const int tl = kg / (PG / 8), e0 = (kg - tl * (PG / 8)) * 8;
+            // lanes 0..7 poll their record until the logic wave has published it (valid bit in the same word)
+            uint32_t rv = REC_VALID;
+            PSTAMP(pst_t0);
+            while (true) {
+                if (lane < 8) rv = const_cast<volatile uint32_t *>(ring)[tl * PG + e0 + lane];
+                if (__ballot((rv & REC_VALID) == 0u) == 0ull) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            PSTAMP(pst_t1);
+#ifdef TW_STAMP
+            pst_poll += pst_t1 - pst_t0; pst_tasks += 8;
+#endif
+#pragma unroll 1
+            for (int j = 0; j < 8; ++j) {
+                const int e = e0 + j;
+                if (n0 + e >= N) break;
+                const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)rv, j);
+                const int ax = r & 31, ay = (r >> 5) & 31, b0 = (r >> 10) & 15, o1y0 = (r >> 14) & 7, o2x0 = (r >> 17) & 15;
+                const int i1 = 9 + ((r >> 21) & 3), i2 = 6 + ((r >> 23) & 3);
+                const bool pone_pre = (r >> 25) & 1, pone_post = (r >> 26) & 1, pat_pre = (r >> 27) & 1, pat_post = (r >> 28) & 1;
+                const int x = min(max(dc_xc + (dc_xs == 1 ? b0 : dc_xs == 2 ? i2 : dc_xs == 3 ? o2x0 : 0), 0), GS - 1);
+                const int y = min(max(dc_yc + (dc_ys == 1 ? i1 : dc_ys == 2 ? o1y0 : 0), 0), GS - 1);
+                const bool pre = (dc_grp == 0) | ((dc_grp == 1) & pone_pre) | ((dc_grp == 2) & pat_pre);
+                const bool post = (dc_grp == 0) | ((dc_grp == 1) & pone_post) | ((dc_grp == 2) & pat_post);
+                const size_t row = (size_t)(c0 + tl) * N + n0 + e;
+                uint8_t *obs_dst = p.obs + row * (size_t)p.obs_pitch;
+                float *mat_dst = p.matrix + row * (size_t)p.mat_pitch;
+#ifdef TW_PIPE_NO_EMIT
+                if (row == 0xffffffffffull) p.obs[0] = (uint8_t)(ax + ay + b0 + o1y0 + o2x0 + i1 + i2 + x + y + pre + post);
+                continue;
+#endif
+                const int gidx = gpi(x, y), midx = MAT_OFF + y * GS + x;
+                if (pre) { my_img[gidx] = dc_code; my_img[midx] = dc_mval; }
+                wave_sync();
+                if (pone_pre == pone_post && pat_pre == pat_post) {
+                    // common case: obs and matrix see the same grid -> issue every gather before any packing
+                    const char *base = reinterpret_cast<const char *>(my_img + gpi(ax, ay));
+                    uint32_t c[6];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) c[k] = *reinterpret_cast<const uint32_t *>(base + of.rel4[k]);
+                    const int qb = lane < 9 ? 64 + lane : 72;
+                    uint4 m0 = *reinterpret_cast<const uint4 *>(my_img + MAT_OFF + 4 * lane);
+                    uint4 m1 = *reinterpret_cast<const uint4 *>(my_img + MAT_OFF + 4 * qb);
+                    const uint32_t w0 = c[0] | (c[1] << 24), w1 = (c[1] >> 8) | (c[2] << 16), w2 = (c[2] >> 16) | (c[3] << 8);
+                    const uint32_t w3 = c[4] | (c[5] << 24), w4 = c[5] >> 8;
+                    uint4 o;
+                    o.x = (__builtin_amdgcn_alignbit(w1, w0, of.shift) & of.andm[0]) | of.orm[0];
+                    o.y = (__builtin_amdgcn_alignbit(w2, w1, of.shift) & of.andm[1]) | of.orm[1];
+                    o.z = (__builtin_amdgcn_alignbit(w3, w2, of.shift) & of.andm[2]) | of.orm[2];
+                    o.w = (__builtin_amdgcn_alignbit(w4, w3, of.shift) & of.andm[3]) | of.orm[3];
+                    if (of.active) *reinterpret_cast<uint4 *>(obs_dst + 16 * lane) = o;
+                    const int ca = ay * GS + ax;
+                    int dd = ca - 4 * lane;
+                    m0.x = dd == 0 ? M_AGENT : m0.x; m0.y = dd == 1 ? M_AGENT : m0.y;
+                    m0.z = dd == 2 ? M_AGENT : m0.z; m0.w = dd == 3 ? M_AGENT : m0.w;
+                    *reinterpret_cast<uint4 *>(mat_dst + 4 * lane) = m0;
+                    dd = ca - 4 * qb;
+                    m1.x = dd == 0 ? M_AGENT : m1.x; m1.y = dd == 1 ? M_AGENT : m1.y;
+                    m1.z = dd == 2 ? M_AGENT : m1.z; m1.w = dd == 3 ? M_AGENT : m1.w;
+                    if (lane < 9) *reinterpret_cast<uint4 *>(mat_dst + 4 * qb) = m1;
+                } else {
+                    // wall drop / patrol spawn happened in this very step: the matrix sees it, the observation did not
+                    emit_obs_fast(my_img, ax, ay, of, lane, obs_dst);
+                    wave_sync();
+                    if (post && !pre) { my_img[gidx] = dc_code; my_img[midx] = dc_mval; }
+                    wave_sync();
+                    emit_matrix_fast(my_img, ax, ay, lane, mat_dst);
+                }
+                wave_sync();
+                if (pre | post) { my_img[gidx] = C_EMPTY; my_img[midx] = M_FREE; }
+                wave_sync();
+            }
+#ifdef TW_STAMP
+            PSTAMP(pst_t0);
+            pst_work += pst_t0 - pst_t1;
+#endif
+        }
+#ifdef TW_STAMP
+        if (wave == 1 && lane == 0 && blockIdx.x < 64) {
+            g_stamp[blockIdx.x][1] = pst_poll; g_stamp[blockIdx.x][2] = pst_work; g_stamp[blockIdx.x][3] = pst_tasks;
+        }
+#endif
+        __syncthreads();
+        if (tid == 0) { ctrl[0] = 0; ctrl[1] = 0; }
+        __syncthreads();
+    }
+
+    // ---- write the final state (records from the logic lanes, planes from the closed form)
+    if (wave == 0 && lane < PG) {
+        int32_t *r = recs + lane * REC;
+        r[TW_AX] = s.ax; r[TW_AY] = s.ay; r[TW_STEP_COUNT] = s.step_count; r[TW_STEP_MOVE] = s.step_move;
+        r[TW_UP1] = s.up1; r[TW_RIGHT2] = s.right2; r[TW_UPD_LONG] = s.upd_long; r[TW_UPD_HORIZ] = s.upd_horiz;
+        r[TW_RISK] = s.risk; r[TW_FIRST_ROOM2] = s.first_room2; r[TW_EPISODES] = s.episodes;
+        r[TW_LAST_REWARD] = s.last_reward; r[TW_LAST_TERM] = s.last_term; r[TW_LAST_TRUNC] = s.last_trunc;
+        r[TW_T] = (int32_t)s.t; r[TW_ERROR] = 0;
+        r[TW_PONE] = d.pone; r[TW_PATROL] = d.patrol; r[TW_WALL_I1] = d.i1; r[TW_WALL_I2] = d.i2;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { r[TW_OBX + k] = d.b0 + k; r[TW_OBY + k] = 8; }
+        if (V4) {
+            r[TW_O1_VALID] = d.patrol; r[TW_O2_VALID] = d.patrol;
+            if (d.patrol) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { r[TW_O1X + k] = 12; r[TW_O1Y + k] = d.o1y0 + k; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { r[TW_O2X + k] = d.o2x0 + (k & 1); r[TW_O2Y + k] = 4 + (k >> 1); }
+            }
+        }
+    }
+    __syncthreads();
+    if (n0 + wave < N) {
+        const int32_t *r = recs + wave * REC;
+        if (lane < REC) p.rec_out[(size_t)(n0 + wave) * REC + lane] = r[lane];
+        Dyn fd = {r[TW_OBX], r[TW_PONE], r[TW_WALL_I1], r[TW_WALL_I2], r[TW_PATROL], r[TW_O1Y], r[TW_O2X]};
+        const size_t gb = (size_t)(n0 + wave) * NC;
+        for (int c = lane; c < NC; c += 64) {
+            const uint32_t v = analytic_cell(c - (c / GS) * GS, c / GS, fd);
+            p.type_out[gb + c] = (uint8_t)v;
+            p.colour_out[gb + c] = (uint8_t)(v >> 8);
         }
     }
 }
@@ -983,9 +1405,13 @@ struct tw_engine {
     int variant, n_envs, view, device;
     uint64_t seed;
     uint32_t env_id0;
-    uint8_t *type, *colour;
+    uint8_t *type, *colour;         // current state (SoA planes + records)
     int32_t *rec;
-    int envs_per_wave;      // 0 = auto
+    uint8_t *type2, *colour2;       // ping-pong partner written by a pipelined launch, swapped in afterwards
+    int32_t *rec2;
+    int *abnormal;                  // device flag of the pipelined kernel
+    int envs_per_wave;              // 0 = auto
+    int pipeline;                   // 1 = use the pipelined kernel when eligible (TW_PIPELINE=0 disables)
 };
 
 namespace {
@@ -1012,6 +1438,8 @@ Params base_params(const tw_engine *e) {
     Params p;
     memset(&p, 0, sizeof(p));
     p.type = e->type; p.colour = e->colour; p.rec = e->rec;
+    p.type_out = e->type; p.colour_out = e->colour; p.rec_out = e->rec;
+    p.abnormal = e->abnormal; p.only_if_flagged = 0;
     p.n_envs = e->n_envs; p.view = e->view; p.variant = e->variant;
     p.seed_lo = (uint32_t)e->seed; p.seed_hi = (uint32_t)(e->seed >> 32);
     p.env_id0 = e->env_id0;
@@ -1050,6 +1478,20 @@ void launch_variant(const tw_engine *e, const Params &p, hipStream_t st) {
     }
 }
 
+constexpr int PIPE_MIN_T = 8;
+constexpr size_t PIPE_LDS_BYTES = (size_t)(PWAVES * ENV_WORDS + PCH * PG + PG * REC + 4 + PCH * PG) * 4;
+
+int launch_sequential(const tw_engine *e, const Params &p, hipStream_t st) {
+    switch (pick_envs_per_wave(e)) {
+    case 1: launch_variant<1>(e, p, st); break;
+    case 2: launch_variant<2>(e, p, st); break;
+    case 4: launch_variant<4>(e, p, st); break;
+    default: return TW_E_ARG;
+    }
+    HIP_TRY(hipGetLastError());
+    return TW_OK;
+}
+
 int launch_rollout(tw_engine *e, int T, const int32_t *actions, const uint32_t *draws, uint8_t *obs, int obs_pitch,
                    float *matrix, int mat_pitch, float *pos, float *reward, uint8_t *term, uint8_t *trunc, int flags,
                    hipStream_t st) {
@@ -1059,13 +1501,22 @@ int launch_rollout(tw_engine *e, int T, const int32_t *actions, const uint32_t *
     if (obs_pitch > 0) p.obs_pitch = obs_pitch;
     if (mat_pitch > 0) p.mat_pitch = mat_pitch;
     if (p.obs_pitch < e->view * e->view * 3 || p.mat_pitch < NC) return TW_E_ARG;
-    switch (pick_envs_per_wave(e)) {
-    case 1: launch_variant<1>(e, p, st); break;
-    case 2: launch_variant<2>(e, p, st); break;
-    case 4: launch_variant<4>(e, p, st); break;
-    default: return TW_E_ARG;
-    }
+    const bool pipe = e->pipeline && T >= PIPE_MIN_T && (flags & TW_F_AUTORESET) && params_fast(e, p);
+    if (!pipe) return launch_sequential(e, p, st);
+    // pipelined launch: cur -> next, with the sequential kernel as a flag-gated fallback from the same input
+    p.type_out = e->type2; p.colour_out = e->colour2; p.rec_out = e->rec2;
+    HIP_TRY(hipMemsetAsync(e->abnormal, 0, sizeof(int), st));
+    const int grid = (e->n_envs + PG - 1) / PG;
+    if (e->variant == 4) hipLaunchKernelGGL((tw_pipe_kernel<4>), dim3(grid), dim3(64 * PWAVES), PIPE_LDS_BYTES, st, p);
+    else hipLaunchKernelGGL((tw_pipe_kernel<6>), dim3(grid), dim3(64 * PWAVES), PIPE_LDS_BYTES, st, p);
     HIP_TRY(hipGetLastError());
+    p.only_if_flagged = 1;
+    int rc = launch_sequential(e, p, st);
+    if (rc != TW_OK) return rc;
+    uint8_t *t8; int32_t *t32;
+    t8 = e->type; e->type = e->type2; e->type2 = t8;
+    t8 = e->colour; e->colour = e->colour2; e->colour2 = t8;
+    t32 = e->rec; e->rec = e->rec2; e->rec2 = t32;
     return TW_OK;
 }
 
@@ -1084,15 +1535,24 @@ int tw_create(tw_engine **out, int variant, int n_envs, int view_size, int devic
     e->seed = seed; e->env_id0 = env_id0;
     const char *epw = getenv("TW_ENVS_PER_WAVE");
     e->envs_per_wave = epw ? atoi(epw) : 0;
-    hipError_t r1 = hipMalloc((void **)&e->type, (size_t)n_envs * NC);
-    hipError_t r2 = hipMalloc((void **)&e->colour, (size_t)n_envs * NC);
-    hipError_t r3 = hipMalloc((void **)&e->rec, (size_t)n_envs * REC * sizeof(int32_t));
-    if (r1 != hipSuccess || r2 != hipSuccess || r3 != hipSuccess) {
-        if (e->type) (void)hipFree(e->type);
-        if (e->colour) (void)hipFree(e->colour);
-        if (e->rec) (void)hipFree(e->rec);
-        free(e);
-        return hip_fail(r1 != hipSuccess ? r1 : (r2 != hipSuccess ? r2 : r3));
+    const char *pl = getenv("TW_PIPELINE");
+    e->pipeline = pl ? atoi(pl) : 1;
+    hipError_t rr[7];
+    rr[0] = hipMalloc((void **)&e->type, (size_t)n_envs * NC);
+    rr[1] = hipMalloc((void **)&e->colour, (size_t)n_envs * NC);
+    rr[2] = hipMalloc((void **)&e->rec, (size_t)n_envs * REC * sizeof(int32_t));
+    rr[3] = hipMalloc((void **)&e->type2, (size_t)n_envs * NC);
+    rr[4] = hipMalloc((void **)&e->colour2, (size_t)n_envs * NC);
+    rr[5] = hipMalloc((void **)&e->rec2, (size_t)n_envs * REC * sizeof(int32_t));
+    rr[6] = hipMalloc((void **)&e->abnormal, sizeof(int));
+    for (int i = 0; i < 7; ++i)
+        if (rr[i] != hipSuccess) { hipError_t bad = rr[i]; tw_destroy(e); return hip_fail(bad); }
+    {   // the pipelined kernel needs > 64 KB of dynamic LDS
+        hipError_t a1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&tw_pipe_kernel<4>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)PIPE_LDS_BYTES);
+        hipError_t a2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&tw_pipe_kernel<6>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)PIPE_LDS_BYTES);
+        if (a1 != hipSuccess || a2 != hipSuccess) e->pipeline = 0;
     }
     Params p = base_params(e);
     hipLaunchKernelGGL(tw_reset_kernel, dim3(n_envs), dim3(64), 0, 0, p, (const uint8_t *)nullptr, 0);
@@ -1106,8 +1566,20 @@ int tw_create(tw_engine **out, int variant, int n_envs, int view_size, int devic
 int tw_destroy(tw_engine *e) {
     if (!e) return TW_E_ARG;
     DeviceGuard g(e->device);
-    (void)hipFree(e->type); (void)hipFree(e->colour); (void)hipFree(e->rec);
+    if (e->type) (void)hipFree(e->type);
+    if (e->colour) (void)hipFree(e->colour);
+    if (e->rec) (void)hipFree(e->rec);
+    if (e->type2) (void)hipFree(e->type2);
+    if (e->colour2) (void)hipFree(e->colour2);
+    if (e->rec2) (void)hipFree(e->rec2);
+    if (e->abnormal) (void)hipFree(e->abnormal);
     free(e);
+    return TW_OK;
+}
+
+int tw_set_pipeline(tw_engine *e, int enable) {
+    if (!e) return TW_E_ARG;
+    e->pipeline = enable ? 1 : 0;
     return TW_OK;
 }
 

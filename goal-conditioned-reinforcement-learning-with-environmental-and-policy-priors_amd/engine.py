@@ -96,6 +96,9 @@ class TwoarmyEngine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def set_pipeline(self, enable):
+        _lib.check(_lib.lib().tw_set_pipeline(self._h, int(bool(enable))), "tw_set_pipeline")
+
     def set_envs_per_wave(self, e):
         _lib.check(_lib.lib().tw_set_envs_per_wave(self._h, int(e)), "tw_set_envs_per_wave")
 

@@ -53,7 +53,8 @@ enum tw_field {
     TW_ERROR = 38,                            /* what the reference would have raised: enum tw_env_error */
     TW_MAX_STEPS = 39,
     TW_EPISODES = 40,                         /* finished episodes (statistics) */
-    TW_LAST_REWARD = 41, TW_LAST_TERM = 42, TW_LAST_TRUNC = 43
+    TW_LAST_REWARD = 41, TW_LAST_TERM = 42, TW_LAST_TRUNC = 43,
+    TW_WALL_I1 = 44, TW_WALL_I2 = 45          /* y / x offset of the two dropped 2x2 wall blocks (valid while TW_PONE) */
 };
 
 enum tw_env_error { TW_ENV_OK = 0, TW_ENV_ATTRIBUTE = 1 /* env action 4/5: minigrid.py:1397 */,
@@ -110,6 +111,11 @@ int tw_rollout(tw_engine *e, int T, const int32_t *actions, const uint32_t *draw
 
 /* Envs per wavefront of the rollout kernel: 1, 2 or 4 (0 = auto from n_envs; also TW_ENVS_PER_WAVE). */
 int tw_set_envs_per_wave(tw_engine *e, int envs_per_wave);
+
+/* Rollouts of >= 8 steps with auto-reset, native layouts and Philox draws use the pipelined kernel
+ * (one logic wave + 15 emission waves per 16 envs) with the sequential kernel as in-stream fallback;
+ * enable = 0 forces the sequential kernel (also TW_PIPELINE=0). */
+int tw_set_pipeline(tw_engine *e, int enable);
 
 /* Fill int32[T][N] with the Philox action-slot policy indices the engine would use for its next
  * T steps (t counted from each env's current TW_T). */

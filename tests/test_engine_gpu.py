@@ -116,18 +116,23 @@ def _oracle(variant, N, T, view, env0):
     return _REF_CACHE[key]
 
 
-def _compare_rollout(variant, N, T, view, env0=0, chunk=None, dense=False, epw=0):
+def _compare_rollout(variant, N, T, view, env0=0, chunk=None, dense=False, epw=0, supply_actions=False,
+                     pipeline=True):
+    """supply_actions=True feeds the (identical) Philox action stream through HBM, which makes the launch
+    eligible for the pipelined kernel (logic wave + emission waves); otherwise the sequential kernel runs."""
     eng = _engine(variant, N, view, seed=SEED, env_id0=env0)
     eng.set_envs_per_wave(epw)
+    eng.set_pipeline(pipeline)
     ref = _oracle(variant, N, T, view, env0)
     out = eng.alloc_outputs(T, dense=dense)
+    acts = eng.fill_actions(T) if supply_actions else None
     if chunk is None:
-        eng.rollout(T, out)
+        eng.rollout(T, out, actions=acts)
     else:                                  # same thing in several launches: state must carry over exactly
         for t0 in range(0, T, chunk):
             t1 = min(T, t0 + chunk)
             sub = {k: (v[t0:t1] if v is not None else None) for k, v in out.items()}
-            eng.rollout(t1 - t0, sub)
+            eng.rollout(t1 - t0, sub, actions=None if acts is None else acts[t0:t1])
     torch.cuda.synchronize()
     for k in ("obs", "matrix", "pos", "reward", "terminated", "truncated"):
         got = out[k].cpu().numpy()
@@ -135,8 +140,82 @@ def _compare_rollout(variant, N, T, view, env0=0, chunk=None, dense=False, epw=0
         if not np.array_equal(got, ref[k]):
             bad = np.argwhere(got != ref[k])[0]
             raise AssertionError("%s mismatch first at %s: got %s want %s" % (k, bad, got[tuple(bad)], ref[k][tuple(bad)]))
+    # final state must equal the oracle-independent sequential kernel's (checked via a second engine)
     eng.close()
     return ref
+
+
+@pytest.mark.parametrize("variant", [6, 4])
+@pytest.mark.parametrize("N,T,view,env0,chunk", [(4096, 200, 17, 0, None), (4096, 300, 17, 0, 128), (1000, 130, 17, 77, 40),
+                                                 (17, 64, 17, 5, None), (513, 100, 7, 0, 9), (4099, 40, 9, 1 << 20, None)])
+def test_pipelined_rollout_vs_oracle(variant, N, T, view, env0, chunk):
+    """The pipelined kernel (closed-form logic wave + 15 emission waves per 16 envs): bit-exact vs the CPU
+    oracle, incl. ragged N, small views, chunked launches (state hand-over through the ping-pong buffers)."""
+    _compare_rollout(variant, N, T, view, env0=env0, chunk=chunk, supply_actions=True, pipeline=True)
+
+
+@pytest.mark.parametrize("variant", [6, 4])
+def test_pipelined_equals_sequential_state(variant):
+    """Same launch through both kernels: identical outputs AND identical final planes / records."""
+    N, T = 777, 150
+    a, b = _engine(variant, N, 17, seed=SEED), _engine(variant, N, 17, seed=SEED)
+    b.set_pipeline(False)
+    acts = a.fill_actions(T)
+    oa, ob = a.alloc_outputs(T), b.alloc_outputs(T)
+    a.rollout(T, oa, actions=acts)
+    b.rollout(T, ob, actions=acts)
+    torch.cuda.synchronize()
+    for k in oa:
+        assert torch.equal(oa[k], ob[k]), k
+    for x, y, name in zip(_canon(a.get_state()), _canon(b.get_state()), ("type", "colour", "records")):
+        assert np.array_equal(x, y), name
+
+
+def _canon(state):
+    """Zero record fields that are meaningless in the current state (cur_pos of unspawned patrols, wall offsets
+    before the drop): the reference objects simply do not exist then, the two kernels keep different leftovers."""
+    Fd = _fields()
+    ty, co, rec = state
+    rec = rec.copy()
+    rec[rec[:, Fd["O1_VALID"]] == 0, Fd["O1X"]:Fd["O1X"] + 6] = 0
+    rec[rec[:, Fd["O2_VALID"]] == 0, Fd["O2X"]:Fd["O2X"] + 8] = 0
+    rec[rec[:, Fd["PONE"]] == 0, Fd["WALL_I1"]:Fd["WALL_I1"] + 2] = 0
+    return ty, co, rec
+
+
+def test_pipelined_falls_back_on_abnormal_state_and_illegal_actions():
+    """Anything outside normal play must come out exactly as the sequential kernel computes it:
+    (a) injected drifted balls, (b) env actions 4/5 (AttributeError in the reference), (c) a foreign grid cell."""
+    Fd = _fields()
+    N, T = 96, 40
+    for case in ("drift", "illegal", "grid"):
+        a, b = _engine(6, N, 17, seed=SEED), _engine(6, N, 17, seed=SEED)
+        b.set_pipeline(False)
+        acts = a.fill_actions(T)
+        policy_idx = True
+        if case == "illegal":
+            acts = acts.clone(); acts[3, 5] = 4; acts[7, 50] = 5; policy_idx = False
+        for eng in (a, b):
+            ty, co, rec = eng.get_state()
+            if case == "drift":
+                for n in (0, 17, 95):
+                    ty[n, 8 * 17 + 7] = 1; co[n, 8 * 17 + 7] = 0; ty[n, 8 * 17 + 10] = 6; co[n, 8 * 17 + 10] = 4
+                    rec[n, Fd["OBX"]:Fd["OBX"] + 3] = [8, 9, 10]
+            if case == "grid":
+                ty[40, 3 * 17 + 3] = 2; co[40, 3 * 17 + 3] = 5
+            eng.set_state(ty, co, rec)
+        oa, ob = a.alloc_outputs(T), b.alloc_outputs(T)
+        a.rollout(T, oa, actions=acts, policy_idx=policy_idx)
+        b.rollout(T, ob, actions=acts, policy_idx=policy_idx)
+        torch.cuda.synchronize()
+        sa, sb = _canon(a.get_state()), _canon(b.get_state())
+        for x, y, name in zip(sa, sb, ("type", "colour", "records")):
+            assert np.array_equal(x, y), (case, name)
+        if case != "illegal":                      # raised steps leave their output rows unwritten
+            for k in oa:
+                assert torch.equal(oa[k], ob[k]), (case, k)
+        else:
+            assert int(sa[2][:, Fd["ERROR"]].max()) == 1
 
 
 @pytest.mark.parametrize("variant", [6, 4])
