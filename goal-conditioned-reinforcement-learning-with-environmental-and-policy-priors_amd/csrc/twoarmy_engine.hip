@@ -54,12 +54,16 @@ constexpr uint32_t M_WALL = 0xbf666666u;   // -0.9f
 constexpr uint32_t M_BALL = 0xbf000000u;   // -0.5f
 constexpr uint32_t M_AGENT = 0x3e99999au;  //  0.3f
 
-// per-env LDS image: wall-padded grid codes gp[33][33] (x in -8..24, y in -16..16) + float matrix
-constexpr int GPW = 33, GPH = 33, GPX0 = 8, GPY0 = 16;
-constexpr int GP_WORDS = GPW * GPH;        // 1089
-constexpr int MAT_OFF = 1092;              // 16-byte aligned
+// per-env LDS image: wall-padded grid codes, x in -8..24, y in -16..16, stored x-major ("transposed")
+// with a y pitch of 35 words, plus the float matrix image.  The observation walks view cells in
+// (x, y) order, so x-major makes a lane's six cells (nearly) consecutive words; pitch 35 makes the six
+// gather instructions at most 2-way bank conflicted (row-major pitch 33 was 11-way: SQ_LDS_BANK_CONFLICT
+// was 41 % of the kernel's cycles).
+constexpr int GPW = 33, GPX0 = 8, GPY0 = 16, GPP = 35;
+constexpr int GP_WORDS = GPW * GPP;        // 1155
+constexpr int MAT_OFF = 1156;              // 16-byte aligned
 constexpr int MAT_WORDS = 292;             // 289 + 3 pad (zeros)
-constexpr int ENV_WORDS = MAT_OFF + MAT_WORDS;   // 1384
+constexpr int ENV_WORDS = MAT_OFF + MAT_WORDS;   // 1448
 constexpr int STAGE_WORDS = 220;
 
 enum { R_STEP = 0, R_RISK = 1, R_HIT = 2, R_ROOM2 = 3, R_GOAL = 4 };
@@ -201,7 +205,7 @@ __device__ __forceinline__ bool normal_mode(const EnvS &s) {
 }
 
 __device__ __forceinline__ bool inb(int x, int y) { return (unsigned)x < (unsigned)GS && (unsigned)y < (unsigned)GS; }
-__device__ __forceinline__ int gpi(int x, int y) { return (y + GPY0) * GPW + x + GPX0; }
+__device__ __forceinline__ int gpi(int x, int y) { return (x + GPX0) * GPP + y + GPY0; }
 
 // One workgroup == one wavefront: LDS operations of a wave execute in issue order, so cross-lane
 // LDS hand-offs only need the COMPILER to keep program order.  __syncthreads() would also emit
@@ -317,7 +321,7 @@ __device__ __forceinline__ ObsFast make_obs_fast(int lane, int V) {
         int c = c0 + k;
         if (c >= VV) c = 0;
         const int i = c / V, j = c - i * V;
-        f.rel4[k] = f.active ? 4 * ((j - (V - 1)) * GPW + (i - h)) : 0;   // idle lanes read the agent cell
+        f.rel4[k] = f.active ? 4 * ((i - h) * GPP + (j - (V - 1))) : 0;   // idle lanes read the agent cell
     }
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
@@ -392,6 +396,7 @@ __device__ __forceinline__ void regen_env(uint32_t *env, int lane) {
 #ifdef TW_STAMP
 // Diagnostic build only (make stamp): phase cycle shares via s_memtime; never in the shipped library.
 __device__ unsigned long long g_stamp[64][8];
+__device__ unsigned long long g_stamp2[64][16][3];   // per wave: tasks, poll cycles, work cycles
 #define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long _t; \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); \
     st_acc[i] += _t - st_prev; st_prev = _t; __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -527,13 +532,13 @@ __global__ __launch_bounds__(64, (E == 1 ? 4 : 2)) void tw_rollout_kernel(Params
                 const int m6 = s.m6;
                 const int dxb = (m6 <= 1) ? 1 : (m6 <= 3 ? -1 : 0);   // :104-109
                 // row-8 balls (:96-112) as 4 branch-free cell writes
-                uint32_t *row8 = my_env + gpi(0, 8);
+                uint32_t *row8 = my_env + gpi(0, 8);      // row 8 of the x-major image: stride GPP per x
                 uint32_t *mrow8 = my_env + MAT_OFF + 8 * GS;
                 const int b0 = s.obx[0], nb = b0 + dxb;
                 const int cx = dxb > 0 ? b0 : b0 + 2;             // the vacated cell (a ball cell when dxb == 0)
-                row8[cx] = dxb != 0 ? C_EMPTY : C_BALL;
+                row8[cx * GPP] = dxb != 0 ? C_EMPTY : C_BALL;
                 mrow8[cx] = dxb != 0 ? M_FREE : M_BALL;
-                row8[nb] = C_BALL; row8[nb + 1] = C_BALL; row8[nb + 2] = C_BALL;
+                row8[nb * GPP] = C_BALL; row8[(nb + 1) * GPP] = C_BALL; row8[(nb + 2) * GPP] = C_BALL;
                 mrow8[nb] = M_BALL; mrow8[nb + 1] = M_BALL; mrow8[nb + 2] = M_BALL;
                 s.obx[0] = nb; s.obx[1] = nb + 1; s.obx[2] = nb + 2;
                 bool alive = true;
@@ -602,13 +607,13 @@ __global__ __launch_bounds__(64, (E == 1 ? 4 : 2)) void tw_rollout_kernel(Params
             const bool balls_fast = (s.oby[0] == 8) & (s.oby[1] == 8) & (s.oby[2] == 8) & (s.obx[1] == b0 + 1) &
                                     (s.obx[2] == b0 + 2) & ((unsigned)(b0 + dxb - 1) <= 12u) & ((unsigned)(b0 - 1) <= 12u);
             if (balls_fast) {
-                uint32_t *row8 = my_env + gpi(0, 8);
+                uint32_t *row8 = my_env + gpi(0, 8);      // row 8 of the x-major image: stride GPP per x
                 uint32_t *mrow8 = my_env + MAT_OFF + 8 * GS;
                 const int nb = b0 + dxb;
                 const int cx = dxb > 0 ? b0 : b0 + 2;             // the vacated cell (a ball cell when dxb == 0)
-                row8[cx] = dxb != 0 ? C_EMPTY : C_BALL;
+                row8[cx * GPP] = dxb != 0 ? C_EMPTY : C_BALL;
                 mrow8[cx] = dxb != 0 ? M_FREE : M_BALL;
-                row8[nb] = C_BALL; row8[nb + 1] = C_BALL; row8[nb + 2] = C_BALL;
+                row8[nb * GPP] = C_BALL; row8[(nb + 1) * GPP] = C_BALL; row8[(nb + 2) * GPP] = C_BALL;
                 mrow8[nb] = M_BALL; mrow8[nb + 1] = M_BALL; mrow8[nb + 2] = M_BALL;
                 s.obx[0] = nb; s.obx[1] = nb + 1; s.obx[2] = nb + 2;
             } else {
@@ -981,11 +986,16 @@ __device__ __forceinline__ bool pipe_state_ok(const EnvS &s) {
     return ok;
 }
 
-__device__ __forceinline__ uint32_t pack_record(int ax, int ay, const Dyn &d, int pone_pre, int patrol_pre) {
-    return (uint32_t)ax | ((uint32_t)ay << 5) | ((uint32_t)d.b0 << 10) | ((uint32_t)(d.o1y0 & 7) << 14) |
-           ((uint32_t)(d.o2x0 & 15) << 17) | ((uint32_t)((d.i1 - 9) & 3) << 21) | ((uint32_t)((d.i2 - 6) & 3) << 23) |
-           ((uint32_t)pone_pre << 25) | ((uint32_t)d.pone << 26) | ((uint32_t)patrol_pre << 27) |
-           ((uint32_t)d.patrol << 28);
+// 31-bit record of one env-step (bit 31 = valid): everything the emission waves need, including the scalar outputs
+//   0-4 ax  5-9 ay  10-11 b0-6  12-13 o1y0-3  14-16 o2x0-5  17-18 i1-9  19-20 i2-6
+//   21 pone(obs)  22 pone(matrix)  23 patrol(obs)  24 patrol(matrix)  25-27 reward code  28 terminated  29 truncated
+__device__ __forceinline__ uint32_t pack_record(int ax, int ay, const Dyn &d, int pone_pre, int patrol_pre, int reward,
+                                                int terminated, int truncated) {
+    return (uint32_t)ax | ((uint32_t)ay << 5) | ((uint32_t)((d.b0 - 6) & 3) << 10) | ((uint32_t)((d.o1y0 - 3) & 3) << 12) |
+           ((uint32_t)((d.o2x0 - 5) & 7) << 14) | ((uint32_t)((d.i1 - 9) & 3) << 17) | ((uint32_t)((d.i2 - 6) & 3) << 19) |
+           ((uint32_t)pone_pre << 21) | ((uint32_t)d.pone << 22) | ((uint32_t)patrol_pre << 23) |
+           ((uint32_t)d.patrol << 24) | ((uint32_t)reward << 25) | ((uint32_t)(terminated != 0) << 28) |
+           ((uint32_t)(truncated != 0) << 29);
 }
 
 template <int VARIANT>
@@ -995,7 +1005,7 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
     uint32_t *ring = img + PWAVES * ENV_WORDS;                  // [PCH][PG]
     int32_t *recs = reinterpret_cast<int32_t *>(ring + PCH * PG);   // [PG][REC]
     volatile int *ctrl = reinterpret_cast<volatile int *>(recs + PG * REC);   // [0] ready  [1] next task
-    int32_t *acts = const_cast<int32_t *>(reinterpret_cast<volatile int32_t *>(ctrl + 4));   // [PCH][PG] actions of the chunk
+    uint32_t *drw = const_cast<uint32_t *>(reinterpret_cast<volatile uint32_t *>(ctrl + 4));  // [PCH][PG] packed draws + action
 
     constexpr bool V4 = VARIANT == 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1005,7 +1015,7 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
 
     // ---- private static image per wave; records of the block's envs
     for (int i = lane; i < GP_WORDS; i += 64) {
-        const int y = i / GPW - GPY0, x = i - (i / GPW) * GPW - GPX0;
+        const int x = i / GPP - GPX0, y = i - (i / GPP) * GPP - GPY0;
         my_img[i] = inb(x, y) ? static_cell(x, y) : C_WALL;
     }
     for (int c = lane; c < MAT_WORDS; c += 64)
@@ -1036,13 +1046,26 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
     // ---- emission constants of this lane
     const ObsFast of = make_obs_fast(lane, V);
     // dynamic-cell slot of this lane: 0-2 balls, 3-10 wall blocks, 11-13 patrol column, 14-17 patrol square
-    int dc_xc = 0, dc_yc = 0, dc_xs = 0, dc_ys = 0, dc_grp = 3;
+    // Every lane decodes the packed record for itself with per-lane shift/mask constants (the scalar unit is
+    // shared by the CU's four SIMDs and was the emission waves' bottleneck):
+    //   x = xc + ((r >> xsh) & xmask),  y = yc + ((r >> ysh) & ymask),  active = always | ((r >> flagbit) & fmask)
+    // Inactive lanes write to a private trash word instead of being masked off (no exec manipulation).
+    int dc_xc = 0, dc_yc = 0;
+    uint32_t dc_xsh = 0, dc_xmask = 0, dc_ysh = 0, dc_ymask = 0, dc_always = 0, dc_fmask = 0, dc_prebit = 0, dc_postbit = 0;
     uint32_t dc_code = C_BALL, dc_mval = M_BALL;
-    if (lane < 3) { dc_grp = 0; dc_xs = 1; dc_xc = lane; dc_yc = 8; }
-    else if (lane < 7) { const int k = lane - 3; dc_grp = 1; dc_xc = 4 + (k & 1); dc_ys = 1; dc_yc = k >> 1; dc_code = C_WALL; dc_mval = M_WALL; }
-    else if (lane < 11) { const int k = lane - 7; dc_grp = 1; dc_xs = 2; dc_xc = k >> 1; dc_yc = 11 + (k & 1); dc_code = C_WALL; dc_mval = M_WALL; }
-    else if (lane < 14) { dc_grp = 2; dc_xc = 12; dc_ys = 2; dc_yc = lane - 11; }
-    else if (lane < 18) { const int k = lane - 14; dc_grp = 2; dc_xs = 3; dc_xc = k & 1; dc_yc = 4 + (k >> 1); }
+    if (lane < 3) { dc_always = 1; dc_xc = 6 + lane; dc_xsh = 10; dc_xmask = 3; dc_yc = 8; }                       // balls: x = b0 + k
+    else if (lane < 7) { const int k = lane - 3; dc_fmask = 1; dc_prebit = 21; dc_postbit = 22; dc_xc = 4 + (k & 1);
+                         dc_yc = 9 + (k >> 1); dc_ysh = 17; dc_ymask = 3; dc_code = C_WALL; dc_mval = M_WALL; }       // block 1: y = i1 + ..
+    else if (lane < 11) { const int k = lane - 7; dc_fmask = 1; dc_prebit = 21; dc_postbit = 22; dc_xc = 6 + (k >> 1);
+                          dc_xsh = 19; dc_xmask = 3; dc_yc = 11 + (k & 1); dc_code = C_WALL; dc_mval = M_WALL; }      // block 2: x = i2 + ..
+    else if (lane < 14) { dc_fmask = 1; dc_prebit = 23; dc_postbit = 24; dc_xc = 12; dc_yc = 3 + (lane - 11);
+                          dc_ysh = 12; dc_ymask = 3; }                                                                // patrol column: y = o1y0 + k
+    else if (lane < 18) { const int k = lane - 14; dc_fmask = 1; dc_prebit = 23; dc_postbit = 24; dc_xc = 5 + (k & 1);
+                          dc_xsh = 14; dc_xmask = 7; dc_yc = 4 + (k >> 1); }                                          // patrol square: x = o2x0 + ..
+    // y columns 33, 34 of the x-major image are never inside any window: 66 private trash words, bank-conflict free
+    const int trash_g = (lane % GPW) * GPP + 33 + lane / GPW;
+    const int mat_lane_off = (MAT_OFF + 4 * lane) * 4;
+    const int mat_laneb_off = (MAT_OFF + 4 * (lane < 9 ? 64 + lane : 72)) * 4;
 
     // ---- LOGIC state of wave 0 (lane e <-> env n0+e): only the fields the closed-form transition touches
     //      (everything else stays in the LDS copy of the record and is written back unchanged)
@@ -1064,7 +1087,6 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
         d.b0 = r[TW_OBX]; d.pone = r[TW_PONE]; d.i1 = r[TW_WALL_I1]; d.i2 = r[TW_WALL_I2]; d.patrol = r[TW_PATROL];
         d.o1y0 = r[TW_O1Y]; d.o2x0 = r[TW_O2X];
     }
-    const uint32_t env_id = p.env_id0 + (uint32_t)(n0 + lane);
     const bool policy_idx = (p.flags & TW_F_POLICY_IDX) != 0;
     bool bad = false;
 
@@ -1074,8 +1096,24 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
         // retires behind every older store, and the emit waves keep the write queues full)
         for (int i = tid; i < len * PG; i += 64 * PWAVES) {
             const int tl = i / PG, e = i - tl * PG;
-            acts[i] = (n0 + e < N) ? p.actions[(size_t)(c0 + tl) * N + n0 + e] : 0;
+            const int act_in = (n0 + e < N) ? p.actions[(size_t)(c0 + tl) * N + n0 + e] : 0;
             ring[i] = 0u;
+            // The draw counter of an env advances by one per step whatever happens, so every Philox word of
+            // the chunk is known up front: all 16 waves compute them in parallel and the serial logic wave
+            // only reads one packed word per step (bit0 gate==6, 1-2 wall1, 3-4 wall2, 5-6 spawn, 7 coin A, 8 coin B).
+            const uint32_t eid = p.env_id0 + (uint32_t)(n0 + e);
+            const uint32_t tnow = (uint32_t)recs[e * REC + TW_T] + (uint32_t)(c0 + tl);
+            uint32_t w[4], packed = 0;
+            if (V4) {
+                draw_block(p.seed_lo, p.seed_hi, eid, tnow, 0, w);
+                packed = ((w[TW_S_GATE] % 10u) == 6u ? 1u : 0u) | ((w[TW_S_WALL1] & 3u) << 1) | ((w[TW_S_WALL2] & 3u) << 3) |
+                         ((w[TW_S_SPAWN] & 3u) << 5);
+            }
+            draw_block(p.seed_lo, p.seed_hi, eid, tnow, 1, w);
+            packed |= ((w[0] & 1u) << 7) | ((w[1] & 1u) << 8);
+            // action in bits 16..: values outside 0..6 are kept distinguishable (7 = "illegal, was >= 7 -> left", 15 = negative)
+            const uint32_t act_enc = act_in < 0 ? 15u : (act_in > 6 ? 7u : (uint32_t)act_in);
+            drw[i] = packed | (act_enc << 16);
         }
         __syncthreads();
 #ifdef TW_STAMP
@@ -1089,17 +1127,14 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
             PSTAMP(pst_t0);
             __builtin_amdgcn_s_setprio(3);        // the serial chain must win issue arbitration on its SIMD
             for (int tl = 0; tl < len; ++tl) {
-                const int tt = c0 + tl;
                 if (lg_active) {
-                    const size_t idx = (size_t)tt * N + n0 + lane;
-                    int action = acts[tl * PG + lane];
-                    if (policy_idx && action == 4) action = 6;
-                    if (action >= 7) action = 0;
-                    bad |= !(((unsigned)action <= 6u) & (((0x4Fu >> (action & 7)) & 1u) != 0u));
-                    action = min(max(action, 0), 6);
-                    const uint32_t t_now = s.t;
-                    uint32_t dw[4] = {0, 0, 0, 0};
-                    if (V4) draw_block(p.seed_lo, p.seed_hi, env_id, t_now, 0, dw);
+                    const uint32_t dr = drw[tl * PG + lane];
+                    int action = (int)((dr >> 16) & 15u);
+                    bad |= action == 15;                                  // negative action: AttributeError in the reference
+                    if (policy_idx && action == 4) action = 6;            // Env_transact.env_action
+                    if (action >= 7) action = 0;                          // twoarmy_v6.py:85-86
+                    bad |= ((0x4Fu >> action) & 1u) == 0u;                // env actions 4 / 5 raise
+                    
                     s.t += 1;
                     s.step_move += 1;
                     s.m6 = s.m6 == 5 ? 0 : s.m6 + 1;
@@ -1112,7 +1147,7 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
                         if (s.upd_long) {
                             s.upd_horiz = 0;
                             bool go = (s.m4 == 2) | (m6 == 3) | (m6 == 0);
-                            go |= (dw[TW_S_GATE] % 10u) == 6u;
+                            go |= (dr & 1u) != 0u;
                             if (go && d.patrol) {
                                 d.o1y0 += s.up1 ? -1 : 1;
                                 if (s.up1) { if (d.o1y0 == 3) s.up1 = 0; } else { if (d.o1y0 + 2 == 7) s.up1 = 1; }
@@ -1121,7 +1156,7 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
                         if (s.upd_horiz) {
                             s.upd_long = 0;
                             bool go = (m6 != 1);
-                            go |= (dw[TW_S_GATE] % 10u) == 6u;
+                            go |= (dr & 1u) != 0u;
                             if (go && d.patrol) {
                                 d.o2x0 += s.right2 ? 1 : -1;
                                 if (s.right2) { if (d.o2x0 + 1 == 11) s.right2 = 0; } else { if (d.o2x0 == 5) s.right2 = 1; }
@@ -1144,12 +1179,12 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
                     const int pone_pre = d.pone, patrol_pre = d.patrol;
                     // ---- after gen_obs(): wall drop, patrol spawn (twoarmy_v6.py:182-198, v4:181-225)
                     if (!d.pone && (s.ax > 3 || s.ay < 14)) {
-                        d.i1 = V4 ? 9 + (int)(dw[TW_S_WALL1] % 4u) : 11;
-                        d.i2 = V4 ? 6 + (int)(dw[TW_S_WALL2] % 4u) : 8;
+                        d.i1 = V4 ? 9 + (int)((dr >> 1) & 3u) : 11;
+                        d.i2 = V4 ? 6 + (int)((dr >> 3) & 3u) : 8;
                         d.pone = 1;
                     }
                     if (V4 && !d.patrol && s.ay <= 8) {
-                        d.o2x0 = 6 + (int)(dw[TW_S_SPAWN] % 4u);
+                        d.o2x0 = 6 + (int)((dr >> 5) & 3u);
                         d.o1y0 = 4;
                         d.patrol = 1;
                     }
@@ -1174,25 +1209,23 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
                     s.first_room2 = room2 ? 0 : s.first_room2;
                     s.risk += (reward == R_RISK);
                     truncated |= (reward == R_RISK) & (s.risk > 5);
-                    const uint32_t record = pack_record(s.ax, s.ay, d, pone_pre, patrol_pre);
-                    const float2 ps = make_float2((float)s.ay, (float)s.ax);
+                    const int rec_ax = s.ax, rec_ay = s.ay;
+                    const Dyn rec_d = d;
                     if (terminated || truncated) {                        // twoarmy_v6.py:296-318 + auto-reset
                         if (terminated) reward = R_GOAL;
                         s.step_move = 0; s.m6 = 0; s.m4 = 0; s.first_room2 = 1; s.risk = 0;
-                        uint32_t cw[4];
-                        draw_block(p.seed_lo, p.seed_hi, env_id, t_now, 1, cw);
-                        if ((cw[0] & 1u) == 1u) { s.up1 = 0; s.right2 = 1; } else { s.up1 = 1; s.right2 = 0; }
-                        if ((cw[1] & 1u) == 1u) { s.upd_horiz = 0; s.upd_long = 1; } else { s.upd_horiz = 1; s.upd_long = 0; }
+                        const int ca = (dr >> 7) & 1, cb = (dr >> 8) & 1;
+                        s.up1 = 1 - ca; s.right2 = ca;
+                        s.upd_horiz = 1 - cb; s.upd_long = cb;
                         s.episodes += 1;
                         d.pone = 0; d.patrol = 0; d.b0 = 7;
                         s.ax = 3; s.ay = 15; s.step_count = 0;
                     }
                     s.last_reward = reward; s.last_term = terminated; s.last_trunc = truncated;
-                    ring[tl * PG + lane] = record | REC_VALID;      // single-word publish: valid bit + payload together
-                    p.reward[idx] = reward_value(reward);
-                    p.term[idx] = (uint8_t)terminated;
-                    p.trunc[idx] = (uint8_t)truncated;
-                    reinterpret_cast<float2 *>(p.pos)[idx] = ps;
+                    // single-word publish: valid bit + payload together; the logic wave issues NO vector-memory op in
+                    // its loop (reward / terminated / truncated / pos are written by the emission waves from the record)
+                    ring[tl * PG + lane] = pack_record(rec_ax, rec_ay, rec_d, pone_pre, patrol_pre, reward, terminated,
+                                                       truncated) | REC_VALID;
                 }
                 else if (lane < PG) ring[tl * PG + lane] = REC_VALID;   // padding env of a ragged last block
             }
@@ -1224,37 +1257,47 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
 #ifdef TW_STAMP
             pst_poll += pst_t1 - pst_t0; pst_tasks += 8;
 #endif
+            if (lane < 8 && n0 + e0 + lane < N) {      // scalar outputs of the 8 env-steps: one lane each, contiguous rows
+                const size_t srow = (size_t)(c0 + tl) * N + n0 + e0 + lane;
+                p.reward[srow] = reward_value((int)((rv >> 25) & 7u));
+                p.term[srow] = (uint8_t)((rv >> 28) & 1u);
+                p.trunc[srow] = (uint8_t)((rv >> 29) & 1u);
+                reinterpret_cast<float2 *>(p.pos)[srow] = make_float2((float)((rv >> 5) & 31u), (float)(rv & 31u));
+            }
+            const size_t grow = (size_t)(c0 + tl) * N + n0 + e0;          // first output row of the group
+            uint8_t *obs_g = p.obs + grow * (size_t)p.obs_pitch;
+            float *mat_g = p.matrix + grow * (size_t)p.mat_pitch;
 #pragma unroll 1
             for (int j = 0; j < 8; ++j) {
-                const int e = e0 + j;
-                if (n0 + e >= N) break;
+                if (n0 + e0 + j >= N) break;
                 const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)rv, j);
-                const int ax = r & 31, ay = (r >> 5) & 31, b0 = (r >> 10) & 15, o1y0 = (r >> 14) & 7, o2x0 = (r >> 17) & 15;
-                const int i1 = 9 + ((r >> 21) & 3), i2 = 6 + ((r >> 23) & 3);
-                const bool pone_pre = (r >> 25) & 1, pone_post = (r >> 26) & 1, pat_pre = (r >> 27) & 1, pat_post = (r >> 28) & 1;
-                const int x = min(max(dc_xc + (dc_xs == 1 ? b0 : dc_xs == 2 ? i2 : dc_xs == 3 ? o2x0 : 0), 0), GS - 1);
-                const int y = min(max(dc_yc + (dc_ys == 1 ? i1 : dc_ys == 2 ? o1y0 : 0), 0), GS - 1);
-                const bool pre = (dc_grp == 0) | ((dc_grp == 1) & pone_pre) | ((dc_grp == 2) & pat_pre);
-                const bool post = (dc_grp == 0) | ((dc_grp == 1) & pone_post) | ((dc_grp == 2) & pat_post);
-                const size_t row = (size_t)(c0 + tl) * N + n0 + e;
-                uint8_t *obs_dst = p.obs + row * (size_t)p.obs_pitch;
-                float *mat_dst = p.matrix + row * (size_t)p.mat_pitch;
+                const int ax = r & 31, ay = (r >> 5) & 31;
+                uint8_t *obs_dst = obs_g + (size_t)j * p.obs_pitch;
+                float *mat_dst = mat_g + (size_t)j * p.mat_pitch;
 #ifdef TW_PIPE_NO_EMIT
-                if (row == 0xffffffffffull) p.obs[0] = (uint8_t)(ax + ay + b0 + o1y0 + o2x0 + i1 + i2 + x + y + pre + post);
+                if (ax == 99) p.obs[0] = (uint8_t)(ax + ay);
                 continue;
 #endif
-                const int gidx = gpi(x, y), midx = MAT_OFF + y * GS + x;
-                if (pre) { my_img[gidx] = dc_code; my_img[midx] = dc_mval; }
+                // this lane's dynamic cell, decoded from the record with per-lane shift/mask constants
+                const int x = dc_xc + (int)((r >> dc_xsh) & dc_xmask);
+                const int y = dc_yc + (int)((r >> dc_ysh) & dc_ymask);
+                const bool pre = (dc_always | ((r >> dc_prebit) & dc_fmask)) != 0u;
+                const int gcell = gpi(x, y), mcell = MAT_OFF + y * GS + x;
+                const int gidx = pre ? gcell : trash_g, midx = pre ? mcell : trash_g;
+                const int ca = MAT_OFF + ay * GS + ax;
+                my_img[gidx] = dc_code;                                  // unconditional: idle lanes hit their trash word
+                my_img[midx] = dc_mval;
                 wave_sync();
-                if (pone_pre == pone_post && pat_pre == pat_post) {
-                    // common case: obs and matrix see the same grid -> issue every gather before any packing
+                if ((((r >> 21) ^ (r >> 22)) & 5u) == 0u) {
+                    // common case: obs and matrix see the same grid -> one batch of gathers, then pack + store
+                    my_img[lane == 0 ? ca : trash_g] = M_AGENT;           // after the dynamic cells: the agent wins (0.3)
+                    wave_sync();
                     const char *base = reinterpret_cast<const char *>(my_img + gpi(ax, ay));
                     uint32_t c[6];
 #pragma unroll
                     for (int k = 0; k < 6; ++k) c[k] = *reinterpret_cast<const uint32_t *>(base + of.rel4[k]);
-                    const int qb = lane < 9 ? 64 + lane : 72;
-                    uint4 m0 = *reinterpret_cast<const uint4 *>(my_img + MAT_OFF + 4 * lane);
-                    uint4 m1 = *reinterpret_cast<const uint4 *>(my_img + MAT_OFF + 4 * qb);
+                    const uint4 m0 = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(my_img) + mat_lane_off);
+                    const uint4 m1 = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(my_img) + mat_laneb_off);
                     const uint32_t w0 = c[0] | (c[1] << 24), w1 = (c[1] >> 8) | (c[2] << 16), w2 = (c[2] >> 16) | (c[3] << 8);
                     const uint32_t w3 = c[4] | (c[5] << 24), w4 = c[5] >> 8;
                     uint4 o;
@@ -1263,25 +1306,24 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
                     o.z = (__builtin_amdgcn_alignbit(w3, w2, of.shift) & of.andm[2]) | of.orm[2];
                     o.w = (__builtin_amdgcn_alignbit(w4, w3, of.shift) & of.andm[3]) | of.orm[3];
                     if (of.active) *reinterpret_cast<uint4 *>(obs_dst + 16 * lane) = o;
-                    const int ca = ay * GS + ax;
-                    int dd = ca - 4 * lane;
-                    m0.x = dd == 0 ? M_AGENT : m0.x; m0.y = dd == 1 ? M_AGENT : m0.y;
-                    m0.z = dd == 2 ? M_AGENT : m0.z; m0.w = dd == 3 ? M_AGENT : m0.w;
                     *reinterpret_cast<uint4 *>(mat_dst + 4 * lane) = m0;
-                    dd = ca - 4 * qb;
-                    m1.x = dd == 0 ? M_AGENT : m1.x; m1.y = dd == 1 ? M_AGENT : m1.y;
-                    m1.z = dd == 2 ? M_AGENT : m1.z; m1.w = dd == 3 ? M_AGENT : m1.w;
-                    if (lane < 9) *reinterpret_cast<uint4 *>(mat_dst + 4 * qb) = m1;
+                    if (lane < 9) *reinterpret_cast<uint4 *>(mat_dst + 4 * (64 + lane)) = m1;
+                    wave_sync();
+                    my_img[gidx] = C_EMPTY;                               // un-patch (trash words may hold anything)
+                    my_img[midx] = M_FREE;
+                    wave_sync();
+                    my_img[lane == 0 ? ca : trash_g] = M_FREE;            // the agent only ever stands on free / goal / ball cells
                 } else {
                     // wall drop / patrol spawn happened in this very step: the matrix sees it, the observation did not
+                    const bool post = (dc_always | ((r >> dc_postbit) & dc_fmask)) != 0u;
                     emit_obs_fast(my_img, ax, ay, of, lane, obs_dst);
                     wave_sync();
-                    if (post && !pre) { my_img[gidx] = dc_code; my_img[midx] = dc_mval; }
+                    if (post) { my_img[gcell] = dc_code; my_img[mcell] = dc_mval; }
                     wave_sync();
                     emit_matrix_fast(my_img, ax, ay, lane, mat_dst);
+                    wave_sync();
+                    if (post) { my_img[gcell] = C_EMPTY; my_img[mcell] = M_FREE; }
                 }
-                wave_sync();
-                if (pre | post) { my_img[gidx] = C_EMPTY; my_img[midx] = M_FREE; }
                 wave_sync();
             }
 #ifdef TW_STAMP
@@ -1292,6 +1334,9 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
 #ifdef TW_STAMP
         if (wave == 1 && lane == 0 && blockIdx.x < 64) {
             g_stamp[blockIdx.x][1] = pst_poll; g_stamp[blockIdx.x][2] = pst_work; g_stamp[blockIdx.x][3] = pst_tasks;
+        }
+        if (lane == 0 && blockIdx.x < 64) {
+            g_stamp2[blockIdx.x][wave][0] = pst_tasks; g_stamp2[blockIdx.x][wave][1] = pst_poll; g_stamp2[blockIdx.x][wave][2] = pst_work;
         }
 #endif
         __syncthreads();
@@ -1673,6 +1718,9 @@ int tw_gen_obs(tw_engine *e, int view_size, uint8_t *obs, int obs_pitch, void *s
 }
 
 #ifdef TW_STAMP
+int tw_debug_stamps2(unsigned long long *out3072) {
+    return hipMemcpyFromSymbol(out3072, HIP_SYMBOL(g_stamp2), sizeof(unsigned long long) * 3072) == hipSuccess ? 0 : -2;
+}
 int tw_debug_stamps(unsigned long long *out512) {
     return hipMemcpyFromSymbol(out512, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 512) == hipSuccess ? 0 : -2;
 }

@@ -26,3 +26,10 @@ assert lib.tw_debug_stamps(buf) == 0
 a = np.array(buf[:], dtype=np.float64).reshape(64, 8)
 print("v%d: logic wave %.0f cycles/step; emit wave 1: %d tasks, poll %.0f cycles/task, work %.0f cycles/task" %
       (variant, a[:, 0].mean() / T, a[:, 3].mean(), a[:, 1].mean() / a[:, 3].mean(), a[:, 2].mean() / a[:, 3].mean()))
+buf2 = (C.c_ulonglong * 3072)()
+lib.tw_debug_stamps2.argtypes = [C.c_void_p]
+assert lib.tw_debug_stamps2(buf2) == 0
+b = np.array(buf2[:], dtype=np.float64).reshape(64, 16, 3)
+print("per-wave tasks (mean over 64 blocks):", np.round(b[:, :, 0].mean(0)).astype(int).tolist())
+print("per-wave work cycles/task:", np.round(b[:, :, 2].mean(0) / np.maximum(b[:, :, 0].mean(0), 1)).astype(int).tolist())
+print("per-wave poll cycles/task:", np.round(b[:, :, 1].mean(0) / np.maximum(b[:, :, 0].mean(0), 1)).astype(int).tolist())
