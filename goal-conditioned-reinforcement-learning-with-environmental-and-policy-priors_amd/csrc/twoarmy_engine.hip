@@ -76,6 +76,7 @@ struct Params {
     uint8_t *colour_out;
     int32_t *rec_out;
     int *abnormal;            // device flag raised by the pipelined kernel when an env leaves normal play
+    int *abnormal_other;      // the flag of the previous pipelined launch: cleared here instead of a memset node
     int only_if_flagged;      // sequential kernel: run only if *abnormal != 0 (fallback launch)
     int n_envs;
     int view;
@@ -1022,6 +1023,7 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
         my_img[MAT_OFF + c] = c < NC ? mat_of_code(static_cell(c - (c / GS) * GS, c / GS)) : 0u;
     if (lane < REC) recs[wave * REC + lane] = (n0 + wave < N) ? p.rec[(size_t)(n0 + wave) * REC + lane] : 0;
     if (tid == 0) { ctrl[0] = 0; ctrl[1] = 0; }
+    if (blockIdx.x == 0 && tid == 0) *p.abnormal_other = 0;     // stream order: the previous launch's fallback is done
     __syncthreads();
 
     // ---- wave e verifies env n0+e: scalar regime + planes == closed form
@@ -1454,7 +1456,8 @@ struct tw_engine {
     int32_t *rec;
     uint8_t *type2, *colour2;       // ping-pong partner written by a pipelined launch, swapped in afterwards
     int32_t *rec2;
-    int *abnormal;                  // device flag of the pipelined kernel
+    int *abnormal;                  // two device flags of the pipelined kernel, used alternately
+    int parity;
     int envs_per_wave;              // 0 = auto
     int pipeline;                   // 1 = use the pipelined kernel when eligible (TW_PIPELINE=0 disables)
 };
@@ -1484,7 +1487,7 @@ Params base_params(const tw_engine *e) {
     memset(&p, 0, sizeof(p));
     p.type = e->type; p.colour = e->colour; p.rec = e->rec;
     p.type_out = e->type; p.colour_out = e->colour; p.rec_out = e->rec;
-    p.abnormal = e->abnormal; p.only_if_flagged = 0;
+    p.abnormal = e->abnormal; p.abnormal_other = e->abnormal + 1; p.only_if_flagged = 0;
     p.n_envs = e->n_envs; p.view = e->view; p.variant = e->variant;
     p.seed_lo = (uint32_t)e->seed; p.seed_hi = (uint32_t)(e->seed >> 32);
     p.env_id0 = e->env_id0;
@@ -1550,7 +1553,9 @@ int launch_rollout(tw_engine *e, int T, const int32_t *actions, const uint32_t *
     if (!pipe) return launch_sequential(e, p, st);
     // pipelined launch: cur -> next, with the sequential kernel as a flag-gated fallback from the same input
     p.type_out = e->type2; p.colour_out = e->colour2; p.rec_out = e->rec2;
-    HIP_TRY(hipMemsetAsync(e->abnormal, 0, sizeof(int), st));
+    p.abnormal = e->abnormal + e->parity;
+    p.abnormal_other = e->abnormal + (e->parity ^ 1);
+    e->parity ^= 1;
     const int grid = (e->n_envs + PG - 1) / PG;
     if (e->variant == 4) hipLaunchKernelGGL((tw_pipe_kernel<4>), dim3(grid), dim3(64 * PWAVES), PIPE_LDS_BYTES, st, p);
     else hipLaunchKernelGGL((tw_pipe_kernel<6>), dim3(grid), dim3(64 * PWAVES), PIPE_LDS_BYTES, st, p);
@@ -1589,9 +1594,13 @@ int tw_create(tw_engine **out, int variant, int n_envs, int view_size, int devic
     rr[3] = hipMalloc((void **)&e->type2, (size_t)n_envs * NC);
     rr[4] = hipMalloc((void **)&e->colour2, (size_t)n_envs * NC);
     rr[5] = hipMalloc((void **)&e->rec2, (size_t)n_envs * REC * sizeof(int32_t));
-    rr[6] = hipMalloc((void **)&e->abnormal, sizeof(int));
+    rr[6] = hipMalloc((void **)&e->abnormal, 2 * sizeof(int));
     for (int i = 0; i < 7; ++i)
         if (rr[i] != hipSuccess) { hipError_t bad = rr[i]; tw_destroy(e); return hip_fail(bad); }
+    {
+        hipError_t me = hipMemset(e->abnormal, 0, 2 * sizeof(int));
+        if (me != hipSuccess) { tw_destroy(e); return hip_fail(me); }
+    }
     {   // the pipelined kernel needs > 64 KB of dynamic LDS
         hipError_t a1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&tw_pipe_kernel<4>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)PIPE_LDS_BYTES);
