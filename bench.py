@@ -27,11 +27,11 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 
 SEED = 9981                    # reference default, soa/train_ppo.py:25
 
 
-def algorithmic_bytes_per_env_step(view, rollout_t):
+def algorithmic_bytes_per_env_step(view, rollout_t, matrix_bytes=289 * 4):
     """Bytes that must cross HBM per env-step for the design built:
     action 4 + obs V*V*3 + state matrix 289*4 + pos 8 + reward 4 + terminated 1 + truncated 1,
     plus the per-launch load/store of the LDS-resident planes + record amortised over T."""
-    per_step = 4 + view * view * 3 + 289 * 4 + 8 + 4 + 1 + 1
+    per_step = 4 + view * view * 3 + matrix_bytes + 8 + 4 + 1 + 1
     per_launch = 2 * (289 + 289 + 48 * 4)
     return per_step + per_launch / float(rollout_t)
 
@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--mode", default="rollout", choices=["rollout", "step"],
                     help="rollout: ROLLOUT_T steps per launch (headline); step: one tw_step launch per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--matrix-codes", action="store_true",
+                    help="BASELINE configs[4] variant: state matrix as uint8 codes (TW_F_MATRIX_CODE), not the headline")
     args = ap.parse_args()
 
     import torch
@@ -82,8 +84,12 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        ngpu = torch.cuda.device_count()
+        torch.cuda.set_device(local_rank % ngpu)
+        if ngpu >= world:                   # one rank per GPU: RCCL over xGMI
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:                               # rehearsal of the N>1 path on a box with fewer GPUs than ranks
+            dist.init_process_group(backend="gloo")
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -93,7 +99,7 @@ def main():
 
     eng = TwoarmyEngine(variant, N, V, device=dev, seed=SEED, env_id0=rank * N)
     actions = eng.fill_actions(W + K)                      # the engine's own Philox stream, HBM-resident
-    out = eng.alloc_outputs(T)
+    out = eng.alloc_outputs(T, matrix_codes=args.matrix_codes)
 
     def run(t_begin, n_steps):
         t = t_begin
@@ -122,12 +128,12 @@ def main():
         dt = float(tmax.item())
 
     # --- roofline leg: the same kernel timed with HIP events on its own launch stream
-    bpe = algorithmic_bytes_per_env_step(V, T)
+    bpe = algorithmic_bytes_per_env_step(V, T, 289 if args.matrix_codes else 289 * 4)
     iters = max(3, min(50, K // T))
     k_ms = eng.time_rollout(T, out, actions=actions[:T], autoreset=True, iters=iters)
     bytes_per_launch = bpe * N * T
     achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
-    traffic = traffic_from_profile(args.variant, N, T, V)
+    traffic = None if args.matrix_codes else traffic_from_profile(args.variant, N, T, V)
     torch.cuda.synchronize()
 
     if rank == 0:
@@ -137,16 +143,18 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
             "config": {"workload": "MiniGrid-twoarmy-17x17-%s, %d envs/GPU, batched HIP step() only "
-                                   "(BASELINE configs[1])" % (args.variant, N),
+                                   "(BASELINE configs[1])%s" % (args.variant, N, " + uint8 code frames (configs[4] storage)"
+                                                                   if args.matrix_codes else ""),
                        "envs_per_gpu": N, "view": V, "steps_per_launch": T, "autoreset": True,
                        "actions": "Philox(seed=9981) policy indices 0..4 (4->done), resident in HBM",
-                       "outputs_per_step": "obs u8[N,V,V,3] + state_matrix f32[N,289] + pos f32[N,2] + reward f32 + term u8 + trunc u8",
+                       "outputs_per_step": "obs u8[N,V,V,3] + state_matrix %s[N,289] + pos f32[N,2] + reward f32 + term u8 + trunc u8"
+                                          % ("u8-code" if args.matrix_codes else "f32"),
                        "parallelism": "env-sharded x%d, no collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)"
                                            if traffic is not None else None,
-                         "kernel": "tw_rollout_kernel", "kernel_ms": k_ms, "launches_timed": iters,
+                         "kernel": "tw_pipe_kernel (+ flag-gated tw_rollout_kernel fallback launch)" if T >= 8 and os.environ.get("TW_PIPELINE", "1") != "0" else "tw_rollout_kernel", "kernel_ms": k_ms, "launches_timed": iters,
                          "algorithmic_bytes_per_env_step": bpe, "bytes_per_launch": bytes_per_launch,
                          "survey_bytes_per_env_step": 2690, "us_per_env_batch_step": k_ms * 1e3 / T},
         }

@@ -16,6 +16,7 @@ TW_REC_WORDS = 48
 TW_DRAW_WORDS = 8
 TW_F_AUTORESET = 1
 TW_F_POLICY_IDX = 2
+TW_F_MATRIX_CODE = 4
 
 # enum tw_field (include/twoarmy.h)
 FIELDS = dict(AX=0, AY=1, DIR=2, STEP_COUNT=3, STEP_MOVE=4, PONE=5, PATROL=6, UP1=7, RIGHT2=8, UPD_LONG=9,
@@ -69,6 +70,7 @@ _SIGS.update({
     "ppo_adv_norm": (C.c_int, [_vp, _i64, _f, _vp, _vp]),
     "ppo_loss_fwd_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "ppo_gather_stack": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "ppo_gather_stack_u8": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "ppo_age_scan": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
 })
 

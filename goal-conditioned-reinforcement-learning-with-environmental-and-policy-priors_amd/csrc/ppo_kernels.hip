@@ -238,7 +238,14 @@ __global__ void ppo_loss_finalize_kernel(const float *__restrict__ ws, int nbloc
 }
 
 // ------------------------------------------------------------------ stack gather / age scan
-__global__ __launch_bounds__(64) void ppo_gather_stack_kernel(const float *__restrict__ frames, int frame_pitch,
+// frame element -> fp32 policy input: identity for float frames, 4-entry LUT for uint8 code frames (TW_F_MATRIX_CODE)
+__device__ __forceinline__ float frame_value(float v) { return v; }
+__device__ __forceinline__ float frame_value(uint8_t c) {
+    return c == 0 ? 0.9f : (c == 1 ? -0.9f : (c == 2 ? -0.5f : 0.3f));
+}
+
+template <typename FT>
+__global__ __launch_bounds__(64) void ppo_gather_stack_kernel(const FT *__restrict__ frames, int frame_pitch,
                                                               const float *__restrict__ pos_frames, int N,
                                                               const int32_t *__restrict__ k_idx,
                                                               const int32_t *__restrict__ n_idx,
@@ -252,9 +259,10 @@ __global__ __launch_bounds__(64) void ppo_gather_stack_kernel(const float *__res
     const int back = 3 - j;
     const bool use_init = age[b] - back <= 0;
     const size_t row = ((size_t)(k_idx[b] - back) * N + n_idx[b]);
-    const float *src = use_init ? init_frame : frames + row * frame_pitch;
+    const FT *src = frames + row * frame_pitch;
     float *dst = out + ((size_t)b * 4 + j) * TW_CELLS;
-    for (int c = lane; c < TW_CELLS; c += 64) dst[c] = src[c];
+    if (use_init) for (int c = lane; c < TW_CELLS; c += 64) dst[c] = init_frame[c];
+    else for (int c = lane; c < TW_CELLS; c += 64) dst[c] = frame_value(src[c]);
     if (pos_out && lane < 2) {
         const float *ps = use_init ? init_pos : pos_frames + row * 2;
         pos_out[((size_t)b * 4 + j) * 2 + lane] = ps[lane];
@@ -337,8 +345,18 @@ int ppo_gather_stack(const float *frames, int frame_pitch, const float *pos_fram
                      float *out, float *pos_out, void *stream) {
     if (!frames || !k_idx || !n_idx || !age || !init_frame || !out || B <= 0 || frame_pitch < TW_CELLS) return TW_E_ARG;
     if (pos_out && (!pos_frames || !init_pos)) return TW_E_ARG;
-    hipLaunchKernelGGL(ppo_gather_stack_kernel, dim3(B * 4), dim3(64), 0, (hipStream_t)stream, frames, frame_pitch,
+    hipLaunchKernelGGL(ppo_gather_stack_kernel<float>, dim3(B * 4), dim3(64), 0, (hipStream_t)stream, frames, frame_pitch,
                        pos_frames, N, k_idx, n_idx, age, init_frame, init_pos, B, out, pos_out);
+    return check_launch();
+}
+
+int ppo_gather_stack_u8(const uint8_t *frames, int frame_pitch, const float *pos_frames, int N, const int32_t *k_idx,
+                        const int32_t *n_idx, const int32_t *age, const float *init_frame, const float *init_pos, int B,
+                        float *out, float *pos_out, void *stream) {
+    if (!frames || !k_idx || !n_idx || !age || !init_frame || !out || B <= 0 || frame_pitch < TW_CELLS) return TW_E_ARG;
+    if (pos_out && (!pos_frames || !init_pos)) return TW_E_ARG;
+    hipLaunchKernelGGL(ppo_gather_stack_kernel<uint8_t>, dim3(B * 4), dim3(64), 0, (hipStream_t)stream, frames,
+                       frame_pitch, pos_frames, N, k_idx, n_idx, age, init_frame, init_pos, B, out, pos_out);
     return check_launch();
 }
 

@@ -63,7 +63,9 @@ constexpr int GPW = 33, GPX0 = 8, GPY0 = 16, GPP = 35;
 constexpr int GP_WORDS = GPW * GPP;        // 1155
 constexpr int MAT_OFF = 1156;              // 16-byte aligned
 constexpr int MAT_WORDS = 292;             // 289 + 3 pad (zeros)
-constexpr int ENV_WORDS = MAT_OFF + MAT_WORDS;   // 1448
+constexpr int MATC_OFF = MAT_OFF + MAT_WORDS;    // 1448: byte image of the matrix as 2-bit codes (TW_F_MATRIX_CODE)
+constexpr int MATC_BYTES = 304;                 // 289 + pad to 16
+constexpr int ENV_WORDS = MATC_OFF + MATC_BYTES / 4;   // 1524
 constexpr int STAGE_WORDS = 220;
 
 enum { R_STEP = 0, R_RISK = 1, R_HIT = 2, R_ROOM2 = 3, R_GOAL = 4 };
@@ -217,10 +219,18 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Grid.set on the env's LDS image: code plane + float matrix image (no bounds check here).
+// matrix value -> code of the reduced-precision frame plane: 0 free/goal (0.9), 1 wall (-0.9), 2 ball (-0.5), 3 agent (0.3)
+__device__ __forceinline__ uint8_t mcode_of(uint32_t mval) {
+    return mval == M_WALL ? 1 : (mval == M_BALL ? 2 : (mval == M_AGENT ? 3 : 0));
+}
+__device__ __forceinline__ uint8_t *mcb(uint32_t *env) { return reinterpret_cast<uint8_t *>(env + MATC_OFF); }
+__device__ __forceinline__ const uint8_t *mcb(const uint32_t *env) { return reinterpret_cast<const uint8_t *>(env + MATC_OFF); }
+
+// Grid.set on the env's LDS image: code plane + float matrix image + matrix code bytes (no bounds check here).
 __device__ __forceinline__ void put(uint32_t *env, int x, int y, uint32_t code, uint32_t mval) {
     env[gpi(x, y)] = code;
     env[MAT_OFF + y * GS + x] = mval;
+    mcb(env)[y * GS + x] = mcode_of(mval);
 }
 
 // Patrol group move: clear every cell, then put each ball at +d inside try/except (twoarmy_v4.py:119-176).
@@ -384,6 +394,26 @@ __device__ __forceinline__ void emit_matrix_generic(const uint32_t *env, int ax,
     for (int c = lane; c < NC; c += 64) d[c] = c == ca ? M_AGENT : env[MAT_OFF + c];
 }
 
+// Reduced-precision frame plane (TW_F_MATRIX_CODE): uint8[289] codes instead of float[289]; 4x fewer bytes and exact
+// (the four matrix values are a 4-entry LUT).  Fast path: 16-byte aligned destination with a pitch >= 304.
+__device__ __forceinline__ void emit_codes(uint32_t *env, int ax, int ay, int lane, uint8_t *dst, bool fast) {
+    uint8_t *b = mcb(env);
+    const int ca = ay * GS + ax;
+    uint8_t old = 0;
+    wave_sync();
+    if (lane == 0) { old = b[ca]; b[ca] = 3; }                   // the agent's cell
+    wave_sync();
+    if (fast) {
+        if (lane < MATC_BYTES / 16)
+            *reinterpret_cast<uint4 *>(dst + 16 * lane) = *reinterpret_cast<const uint4 *>(b + 16 * lane);
+    } else {
+        for (int c = lane; c < NC; c += 64) dst[c] = b[c];
+    }
+    wave_sync();
+    if (lane == 0) b[ca] = old;
+    wave_sync();
+}
+
 // (re)generate one env's LDS image interior cooperatively (auto-reset / init)
 __device__ __forceinline__ void regen_env(uint32_t *env, int lane) {
     for (int c = lane; c < NC; c += 64) {
@@ -391,6 +421,7 @@ __device__ __forceinline__ void regen_env(uint32_t *env, int lane) {
         const uint32_t code = gen_cell(x, y);
         env[gpi(x, y)] = code;
         env[MAT_OFF + c] = mat_of_code(code);
+        mcb(env)[c] = mcode_of(mat_of_code(code));
     }
 }
 
@@ -438,6 +469,8 @@ __global__ __launch_bounds__(64, (E == 1 ? 4 : 2)) void tw_rollout_kernel(Params
         uint32_t *env = lds_env + e * ENV_WORDS;
         for (int i = lane; i < GP_WORDS; i += 64) env[i] = C_WALL;          // wall padding
         if (lane < MAT_WORDS - NC) env[MAT_OFF + NC + lane] = 0u;
+        if (lane < MATC_BYTES / 4) env[MATC_OFF + lane] = 0u;
+        if (lane + 64 < MATC_BYTES / 4) env[MATC_OFF + 64 + lane] = 0u;
     }
     wave_sync();
 #pragma unroll
@@ -450,6 +483,7 @@ __global__ __launch_bounds__(64, (E == 1 ? 4 : 2)) void tw_rollout_kernel(Params
             const int y = c / GS, x = c - y * GS;
             env[gpi(x, y)] = code;
             env[MAT_OFF + c] = mat_of_code(code);
+            mcb(env)[c] = mcode_of(mat_of_code(code));
         }
     }
     wave_sync();
@@ -468,12 +502,16 @@ __global__ __launch_bounds__(64, (E == 1 ? 4 : 2)) void tw_rollout_kernel(Params
     const bool fast_mat_ok = FAST || (p.matrix && ((uintptr_t)p.matrix & 15u) == 0 && (p.mat_pitch & 3) == 0 &&
                                       p.mat_pitch >= MAT_WORDS);
     const ObsFast of = make_obs_fast(lane, V);
-    const bool layouts_fast = FAST || ((!p.obs || fast_obs_ok) && (!p.matrix || fast_mat_ok));
+    const bool code_mode = !FAST && (p.flags & TW_F_MATRIX_CODE) != 0;     // matrix output = uint8 codes, pitch in bytes
+    const bool fast_code_ok = code_mode && p.matrix && ((uintptr_t)p.matrix & 15u) == 0 && (p.mat_pitch & 15) == 0 &&
+                              p.mat_pitch >= MATC_BYTES;
+    const bool layouts_fast = FAST || ((!p.obs || fast_obs_ok) && (!p.matrix || fast_mat_ok || code_mode));
     const unsigned long long m_active = __ballot(active);
 
     // running output cursors (advance by one time row per step)
     uint8_t *obs_row = has_obs ? p.obs + (size_t)n0 * p.obs_pitch : nullptr;
     float *mat_row = has_mat ? p.matrix + (size_t)n0 * p.mat_pitch : nullptr;
+    uint8_t *matc_row = has_mat ? reinterpret_cast<uint8_t *>(p.matrix) + (size_t)n0 * p.mat_pitch : nullptr;
     const size_t obs_step = (size_t)N * p.obs_pitch, mat_step = (size_t)N * p.mat_pitch;
     size_t idx = (size_t)n0 + lane;                         // [t][n] row of this lane's env
 
@@ -481,7 +519,7 @@ __global__ __launch_bounds__(64, (E == 1 ? 4 : 2)) void tw_rollout_kernel(Params
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev) :: "memory");
 #endif
-    for (int tt = 0; tt < p.T; ++tt, idx += N, obs_row += obs_step, mat_row += mat_step) {
+    for (int tt = 0; tt < p.T; ++tt, idx += N, obs_row += obs_step, mat_row += mat_step, matc_row += mat_step) {
         STAMP(0);
 
         // ---- actions: one coalesced-per-env vector load every 64 steps, parked in LDS
@@ -537,10 +575,13 @@ __global__ __launch_bounds__(64, (E == 1 ? 4 : 2)) void tw_rollout_kernel(Params
                 uint32_t *mrow8 = my_env + MAT_OFF + 8 * GS;
                 const int b0 = s.obx[0], nb = b0 + dxb;
                 const int cx = dxb > 0 ? b0 : b0 + 2;             // the vacated cell (a ball cell when dxb == 0)
+                uint8_t *crow8 = mcb(my_env) + 8 * GS;
                 row8[cx * GPP] = dxb != 0 ? C_EMPTY : C_BALL;
                 mrow8[cx] = dxb != 0 ? M_FREE : M_BALL;
+                crow8[cx] = dxb != 0 ? 0 : 2;
                 row8[nb * GPP] = C_BALL; row8[(nb + 1) * GPP] = C_BALL; row8[(nb + 2) * GPP] = C_BALL;
                 mrow8[nb] = M_BALL; mrow8[nb + 1] = M_BALL; mrow8[nb + 2] = M_BALL;
+                crow8[nb] = 2; crow8[nb + 1] = 2; crow8[nb + 2] = 2;
                 s.obx[0] = nb; s.obx[1] = nb + 1; s.obx[2] = nb + 2;
                 bool alive = true;
                 if (V4) {
@@ -612,10 +653,13 @@ __global__ __launch_bounds__(64, (E == 1 ? 4 : 2)) void tw_rollout_kernel(Params
                 uint32_t *mrow8 = my_env + MAT_OFF + 8 * GS;
                 const int nb = b0 + dxb;
                 const int cx = dxb > 0 ? b0 : b0 + 2;             // the vacated cell (a ball cell when dxb == 0)
+                uint8_t *crow8 = mcb(my_env) + 8 * GS;
                 row8[cx * GPP] = dxb != 0 ? C_EMPTY : C_BALL;
                 mrow8[cx] = dxb != 0 ? M_FREE : M_BALL;
+                crow8[cx] = dxb != 0 ? 0 : 2;
                 row8[nb * GPP] = C_BALL; row8[(nb + 1) * GPP] = C_BALL; row8[(nb + 2) * GPP] = C_BALL;
                 mrow8[nb] = M_BALL; mrow8[nb + 1] = M_BALL; mrow8[nb + 2] = M_BALL;
+                crow8[nb] = 2; crow8[nb + 1] = 2; crow8[nb + 2] = 2;
                 s.obx[0] = nb; s.obx[1] = nb + 1; s.obx[2] = nb + 2;
             } else {
                 bool ok = true;
@@ -815,7 +859,7 @@ __global__ __launch_bounds__(64, (E == 1 ? 4 : 2)) void tw_rollout_kernel(Params
 #pragma unroll
                     for (int k = 0; k < 6; ++k) oc[e][k] = *reinterpret_cast<const uint32_t *>(base + of.rel4[k]);
                 }
-                if (has_mat) {
+                if (has_mat && !code_mode) {
                     mq[e][0] = *reinterpret_cast<const uint4 *>(env + MAT_OFF + 4 * lane);
                     mq[e][1] = *reinterpret_cast<const uint4 *>(env + MAT_OFF + 4 * qb);
                 }
@@ -841,7 +885,9 @@ __global__ __launch_bounds__(64, (E == 1 ? 4 : 2)) void tw_rollout_kernel(Params
                     if (of.active && valid_e)
                         *reinterpret_cast<uint4 *>(obs_row + (size_t)e * p.obs_pitch + 16 * lane) = o;
                 }
-                if (has_mat) {
+                if (has_mat && code_mode) {
+                    if (valid_e) emit_codes(lds_env + e * ENV_WORDS, cax[e], cay[e], lane, matc_row + (size_t)e * p.mat_pitch, fast_code_ok);
+                } else if (has_mat) {
                     const int ca = cay[e] * GS + cax[e];
                     float *dst = mat_row + (size_t)e * p.mat_pitch;
 #pragma unroll
@@ -878,9 +924,10 @@ __global__ __launch_bounds__(64, (E == 1 ? 4 : 2)) void tw_rollout_kernel(Params
                 for (int e = 0; e < E; ++e) {
                     if (!__builtin_amdgcn_readlane(have_obs, e)) continue;
                     const int ax = __builtin_amdgcn_readlane(s.ax, e), ay = __builtin_amdgcn_readlane(s.ay, e);
-                    const uint32_t *env = lds_env + e * ENV_WORDS;
+                    uint32_t *env = lds_env + e * ENV_WORDS;
                     float *dst = mat_row + (size_t)e * p.mat_pitch;
-                    if (fast_mat_ok) emit_matrix_fast(env, ax, ay, lane, dst);
+                    if (code_mode) emit_codes(env, ax, ay, lane, matc_row + (size_t)e * p.mat_pitch, fast_code_ok);
+                    else if (fast_mat_ok) emit_matrix_fast(env, ax, ay, lane, dst);
                     else emit_matrix_generic(env, ax, ay, lane, dst);
                 }
             }
@@ -1021,6 +1068,10 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
     }
     for (int c = lane; c < MAT_WORDS; c += 64)
         my_img[MAT_OFF + c] = c < NC ? mat_of_code(static_cell(c - (c / GS) * GS, c / GS)) : 0u;
+    for (int c = lane; c < MATC_BYTES; c += 64)
+        mcb(my_img)[c] = c < NC ? mcode_of(mat_of_code(static_cell(c - (c / GS) * GS, c / GS))) : 0;
+    const bool code_mode = (p.flags & TW_F_MATRIX_CODE) != 0;
+    uint8_t *img_bytes = reinterpret_cast<uint8_t *>(my_img);
     if (lane < REC) recs[wave * REC + lane] = (n0 + wave < N) ? p.rec[(size_t)(n0 + wave) * REC + lane] : 0;
     if (tid == 0) { ctrl[0] = 0; ctrl[1] = 0; }
     if (blockIdx.x == 0 && tid == 0) *p.abnormal_other = 0;     // stream order: the previous launch's fallback is done
@@ -1055,6 +1106,7 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
     int dc_xc = 0, dc_yc = 0;
     uint32_t dc_xsh = 0, dc_xmask = 0, dc_ysh = 0, dc_ymask = 0, dc_always = 0, dc_fmask = 0, dc_prebit = 0, dc_postbit = 0;
     uint32_t dc_code = C_BALL, dc_mval = M_BALL;
+    const uint8_t dc_mcode = (lane >= 3 && lane < 11) ? 1 : 2;
     if (lane < 3) { dc_always = 1; dc_xc = 6 + lane; dc_xsh = 10; dc_xmask = 3; dc_yc = 8; }                       // balls: x = b0 + k
     else if (lane < 7) { const int k = lane - 3; dc_fmask = 1; dc_prebit = 21; dc_postbit = 22; dc_xc = 4 + (k & 1);
                          dc_yc = 9 + (k >> 1); dc_ysh = 17; dc_ymask = 3; dc_code = C_WALL; dc_mval = M_WALL; }       // block 1: y = i1 + ..
@@ -1276,6 +1328,7 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
                 const int ax = r & 31, ay = (r >> 5) & 31;
                 uint8_t *obs_dst = obs_g + (size_t)j * p.obs_pitch;
                 float *mat_dst = mat_g + (size_t)j * p.mat_pitch;
+                uint8_t *matc_dst = reinterpret_cast<uint8_t *>(p.matrix) + (grow + j) * (size_t)p.mat_pitch;
 #ifdef TW_PIPE_NO_EMIT
                 if (ax == 99) p.obs[0] = (uint8_t)(ax + ay);
                 continue;
@@ -1287,12 +1340,16 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
                 const int gcell = gpi(x, y), mcell = MAT_OFF + y * GS + x;
                 const int gidx = pre ? gcell : trash_g, midx = pre ? mcell : trash_g;
                 const int ca = MAT_OFF + ay * GS + ax;
+                const int bidx = pre ? MATC_OFF * 4 + y * GS + x : trash_g * 4;       // byte image of the matrix codes
+                const int bca = lane == 0 ? MATC_OFF * 4 + ay * GS + ax : trash_g * 4;
                 my_img[gidx] = dc_code;                                  // unconditional: idle lanes hit their trash word
                 my_img[midx] = dc_mval;
+                if (code_mode) img_bytes[bidx] = dc_mcode;
                 wave_sync();
                 if ((((r >> 21) ^ (r >> 22)) & 5u) == 0u) {
                     // common case: obs and matrix see the same grid -> one batch of gathers, then pack + store
                     my_img[lane == 0 ? ca : trash_g] = M_AGENT;           // after the dynamic cells: the agent wins (0.3)
+                    if (code_mode) img_bytes[bca] = 3;
                     wave_sync();
                     const char *base = reinterpret_cast<const char *>(my_img + gpi(ax, ay));
                     uint32_t c[6];
@@ -1308,23 +1365,31 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
                     o.z = (__builtin_amdgcn_alignbit(w3, w2, of.shift) & of.andm[2]) | of.orm[2];
                     o.w = (__builtin_amdgcn_alignbit(w4, w3, of.shift) & of.andm[3]) | of.orm[3];
                     if (of.active) *reinterpret_cast<uint4 *>(obs_dst + 16 * lane) = o;
-                    *reinterpret_cast<uint4 *>(mat_dst + 4 * lane) = m0;
-                    if (lane < 9) *reinterpret_cast<uint4 *>(mat_dst + 4 * (64 + lane)) = m1;
+                    if (!code_mode) {
+                        *reinterpret_cast<uint4 *>(mat_dst + 4 * lane) = m0;
+                        if (lane < 9) *reinterpret_cast<uint4 *>(mat_dst + 4 * (64 + lane)) = m1;
+                    } else if (lane < MATC_BYTES / 16) {
+                        *reinterpret_cast<uint4 *>(matc_dst + 16 * lane) =
+                            *reinterpret_cast<const uint4 *>(img_bytes + MATC_OFF * 4 + 16 * lane);
+                    }
                     wave_sync();
                     my_img[gidx] = C_EMPTY;                               // un-patch (trash words may hold anything)
                     my_img[midx] = M_FREE;
+                    if (code_mode) img_bytes[bidx] = 0;
                     wave_sync();
                     my_img[lane == 0 ? ca : trash_g] = M_FREE;            // the agent only ever stands on free / goal / ball cells
+                    if (code_mode) img_bytes[bca] = 0;
                 } else {
                     // wall drop / patrol spawn happened in this very step: the matrix sees it, the observation did not
                     const bool post = (dc_always | ((r >> dc_postbit) & dc_fmask)) != 0u;
                     emit_obs_fast(my_img, ax, ay, of, lane, obs_dst);
                     wave_sync();
-                    if (post) { my_img[gcell] = dc_code; my_img[mcell] = dc_mval; }
+                    if (post) { my_img[gcell] = dc_code; my_img[mcell] = dc_mval; mcb(my_img)[y * GS + x] = dc_mcode; }
                     wave_sync();
-                    emit_matrix_fast(my_img, ax, ay, lane, mat_dst);
+                    if (code_mode) emit_codes(my_img, ax, ay, lane, matc_dst, true);
+                    else emit_matrix_fast(my_img, ax, ay, lane, mat_dst);
                     wave_sync();
-                    if (post) { my_img[gcell] = C_EMPTY; my_img[mcell] = M_FREE; }
+                    if (post | pre) { my_img[gcell] = C_EMPTY; my_img[mcell] = M_FREE; mcb(my_img)[y * GS + x] = 0; }
                 }
                 wave_sync();
             }
@@ -1506,17 +1571,21 @@ int pick_envs_per_wave(const tw_engine *e) {
     return 1;
 }
 
-bool params_fast(const tw_engine *e, const Params &p) {
+bool params_fast(const tw_engine *e, const Params &p, bool allow_codes) {
     const int chunk = ((e->view * e->view * 3 + 15) >> 4) << 4;
+    const bool codes = (p.flags & TW_F_MATRIX_CODE) != 0;
+    if (codes && !allow_codes) return false;
+    const bool mat_ok = codes ? ((p.mat_pitch & 15) == 0 && p.mat_pitch >= MATC_BYTES)
+                              : ((p.mat_pitch & 3) == 0 && p.mat_pitch >= MAT_WORDS);
     return p.obs && p.matrix && p.pos && p.reward && p.term && p.trunc && p.actions && !p.draws &&
            ((uintptr_t)p.obs & 15u) == 0 && (p.obs_pitch & 15) == 0 && p.obs_pitch >= chunk &&
-           ((uintptr_t)p.matrix & 15u) == 0 && (p.mat_pitch & 3) == 0 && p.mat_pitch >= MAT_WORDS;
+           ((uintptr_t)p.matrix & 15u) == 0 && mat_ok;
 }
 
 template <int E>
 void launch_variant(const tw_engine *e, const Params &p, hipStream_t st) {
     const int grid = (e->n_envs + E - 1) / E;
-    const bool fast = params_fast(e, p);
+    const bool fast = params_fast(e, p, false);
     if (e->variant == 4) {
         if (fast) hipLaunchKernelGGL((tw_rollout_kernel<E, 4, true>), dim3(grid), dim3(64), 0, st, p);
         else hipLaunchKernelGGL((tw_rollout_kernel<E, 4, false>), dim3(grid), dim3(64), 0, st, p);
@@ -1527,7 +1596,7 @@ void launch_variant(const tw_engine *e, const Params &p, hipStream_t st) {
 }
 
 constexpr int PIPE_MIN_T = 8;
-constexpr size_t PIPE_LDS_BYTES = (size_t)(PWAVES * ENV_WORDS + PCH * PG + PG * REC + 4 + PCH * PG) * 4;
+constexpr size_t PIPE_LDS_BYTES = (size_t)(PWAVES * ENV_WORDS + PCH * PG + PG * REC + 4 + PCH * PG) * 4;   // ~117 KB
 
 int launch_sequential(const tw_engine *e, const Params &p, hipStream_t st) {
     switch (pick_envs_per_wave(e)) {
@@ -1548,8 +1617,8 @@ int launch_rollout(tw_engine *e, int T, const int32_t *actions, const uint32_t *
     p.reward = reward; p.term = term; p.trunc = trunc; p.flags = flags;
     if (obs_pitch > 0) p.obs_pitch = obs_pitch;
     if (mat_pitch > 0) p.mat_pitch = mat_pitch;
-    if (p.obs_pitch < e->view * e->view * 3 || p.mat_pitch < NC) return TW_E_ARG;
-    const bool pipe = e->pipeline && T >= PIPE_MIN_T && (flags & TW_F_AUTORESET) && params_fast(e, p);
+    if (p.obs_pitch < e->view * e->view * 3 || p.mat_pitch < NC) return TW_E_ARG;   // pitch: floats, or bytes with TW_F_MATRIX_CODE
+    const bool pipe = e->pipeline && T >= PIPE_MIN_T && (flags & TW_F_AUTORESET) && params_fast(e, p, true);
     if (!pipe) return launch_sequential(e, p, st);
     // pipelined launch: cur -> next, with the sequential kernel as a flag-gated fallback from the same input
     p.type_out = e->type2; p.colour_out = e->colour2; p.rec_out = e->rec2;

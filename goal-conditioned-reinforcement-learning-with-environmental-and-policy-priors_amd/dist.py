@@ -17,7 +17,8 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # RCCL needs one GPU per rank; fewer GPUs than ranks (rehearsals, CPU tests) -> gloo
+            backend = "nccl" if torch.cuda.is_available() and torch.cuda.device_count() >= world else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend=backend, device_id=torch.device("cuda", local_rank))

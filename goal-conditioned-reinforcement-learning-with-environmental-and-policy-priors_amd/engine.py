@@ -8,10 +8,12 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import FIELDS, TW_CELLS, TW_DRAW_WORDS, TW_F_AUTORESET, TW_F_POLICY_IDX, TW_REC_WORDS
+from ._lib import FIELDS, TW_CELLS, TW_DRAW_WORDS, TW_F_AUTORESET, TW_F_MATRIX_CODE, TW_F_POLICY_IDX, TW_REC_WORDS
 
 REWARD_VALUES = (-0.01, -0.1, -0.9, 0.2, 0.9)
 MAT_PITCH = 292                       # floats per env matrix in the native layout (289 + 3 zero pad)
+MATC_PITCH = 304                      # bytes per env matrix in the code layout (TW_F_MATRIX_CODE; 289 + 15 pad)
+MATRIX_CODE_VALUES = (0.9, -0.9, -0.5, 0.3)     # code -> Env_transact.matrix_env value (free/goal, wall, ball, agent)
 
 
 def obs_pitch_for(view):
@@ -103,22 +105,30 @@ class TwoarmyEngine:
         _lib.check(_lib.lib().tw_set_envs_per_wave(self._h, int(e)), "tw_set_envs_per_wave")
 
     # ------------------------------------------------------------------ buffers
-    def alloc_outputs(self, T=None, obs=True, matrix=True, dense=False):
+    def alloc_outputs(self, T=None, obs=True, matrix=True, dense=False, matrix_codes=False):
         """Output tensors for step (T=None -> [N,...]) or rollout ([T,N,...]).
 
         Native layout (dense=False): obs rows padded to 16 bytes (880 for V=17) and matrix rows to
-        292 floats; the returned tensors are [..., V, V, 3] / [..., 289] strided views of them."""
+        292 floats; the returned tensors are [..., V, V, 3] / [..., 289] strided views of them.
+        matrix_codes=True: the matrix is uint8 codes (rows of 304 bytes natively), see TW_F_MATRIX_CODE;
+        a uint8 matrix tensor selects that mode in step/rollout."""
         N, V = self.num_envs, self.view_size
         lead = (N,) if T is None else (T, N)
         d = self.device
         nb = V * V * 3
         if dense:
             o = torch.empty(lead + (V, V, 3), dtype=torch.uint8, device=d) if obs else None
-            m = torch.empty(lead + (TW_CELLS,), dtype=torch.float32, device=d) if matrix else None
+            m = torch.empty(lead + (TW_CELLS,), dtype=torch.uint8 if matrix_codes else torch.float32, device=d) \
+                if matrix else None
         else:
             o = torch.empty(lead + (obs_pitch_for(V),), dtype=torch.uint8, device=d)[..., :nb].view(lead + (V, V, 3)) \
                 if obs else None
-            m = torch.empty(lead + (MAT_PITCH,), dtype=torch.float32, device=d)[..., :TW_CELLS] if matrix else None
+            if not matrix:
+                m = None
+            elif matrix_codes:
+                m = torch.empty(lead + (MATC_PITCH,), dtype=torch.uint8, device=d)[..., :TW_CELLS]
+            else:
+                m = torch.empty(lead + (MAT_PITCH,), dtype=torch.float32, device=d)[..., :TW_CELLS]
         return dict(
             obs=o, matrix=m,
             pos=torch.empty(lead + (2,), dtype=torch.float32, device=d),
@@ -134,10 +144,25 @@ class TwoarmyEngine:
         _lib.check(_lib.lib().tw_reset(self._h, _dense(mask, torch.uint8), op, opitch, self._stream()), "tw_reset")
         return obs
 
+    @staticmethod
+    def _matrix_arg(m, lead, flags):
+        """(pointer, pitch, flags): a uint8 matrix tensor means code frames (pitch in bytes)."""
+        if m is not None and m.dtype == torch.uint8:
+            mp, mpitch = _pitched(m, lead, (TW_CELLS,), torch.uint8)
+            return mp, mpitch, flags | TW_F_MATRIX_CODE
+        mp, mpitch = _pitched(m, lead, (TW_CELLS,), torch.float32)
+        return mp, mpitch, flags
+
+    @staticmethod
+    def decode_matrix(codes):
+        """uint8 code frames -> the float matrix of Env_transact.matrix_env (env_buffer.py:300-336)."""
+        lut = torch.tensor(MATRIX_CODE_VALUES, dtype=torch.float32, device=codes.device)
+        return lut[codes.long()]
+
     def _launch(self, fn, name, lead, T, actions, draws, out, flags):
         V = self.view_size
         op, opitch = _pitched(out.get("obs"), lead, (V, V, 3), torch.uint8)
-        mp, mpitch = _pitched(out.get("matrix"), lead, (TW_CELLS,), torch.float32)
+        mp, mpitch, flags = self._matrix_arg(out.get("matrix"), lead, flags)
         for k, dt in (("pos", torch.float32), ("reward", torch.float32), ("terminated", torch.uint8),
                       ("truncated", torch.uint8)):
             t = out.get(k)
@@ -181,7 +206,7 @@ class TwoarmyEngine:
         lead = (T, self.num_envs)
         flags = (TW_F_AUTORESET if autoreset else 0) | TW_F_POLICY_IDX
         op, opitch = _pitched(out.get("obs"), lead, (V, V, 3), torch.uint8)
-        mp, mpitch = _pitched(out.get("matrix"), lead, (TW_CELLS,), torch.float32)
+        mp, mpitch, flags = self._matrix_arg(out.get("matrix"), lead, flags)
         _lib.check(_lib.lib().tw_time_rollout(
             self._h, T, _dense(actions, torch.int32), op, opitch, mp, mpitch,
             _ptr(out.get("pos")), _ptr(out.get("reward")), _ptr(out.get("terminated")), _ptr(out.get("truncated")),

@@ -83,14 +83,17 @@ def ppo_losses(probs, value, action, old_logp, adv, target_v, clip=0.1, ent_coef
 
 
 def gather_stack(frames, pos_frames, k_idx, n_idx, age, init_frame, init_pos):
-    """frames [K,N,pitch>=289] (may be a [..., :289] view of a 292-pitched buffer) -> ([B,4,289], [B,4,2])."""
+    """frames [K,N,pitch>=289] (may be a [..., :289] view of a 292-pitched buffer) -> ([B,4,289], [B,4,2]).
+    uint8 frames are matrix codes (TW_F_MATRIX_CODE) and are expanded to fp32 on the fly."""
     K, N = frames.shape[:2]
     pitch = frames.stride(1)
     assert frames.stride(2) == 1 and frames.stride(0) == N * pitch
     B = k_idx.numel()
     out = torch.empty((B, 4, 289), dtype=torch.float32, device=frames.device)
     pos_out = torch.empty((B, 4, 2), dtype=torch.float32, device=frames.device) if pos_frames is not None else None
-    _lib.check(_lib.lib().ppo_gather_stack(
+    assert frames.dtype in (torch.float32, torch.uint8)
+    fn = _lib.lib().ppo_gather_stack if frames.dtype == torch.float32 else _lib.lib().ppo_gather_stack_u8
+    _lib.check(fn(
         C.c_void_p(frames.data_ptr()), pitch, _p(pos_frames, torch.float32), N, _p(k_idx, torch.int32),
         _p(n_idx, torch.int32), _p(age, torch.int32), _p(init_frame, torch.float32), _p(init_pos, torch.float32), B,
         _p(out), _p(pos_out), _stream(frames)), "ppo_gather_stack")

@@ -15,13 +15,20 @@ GOAL_YX = (2.0, 14.0)
 
 
 class VecPPOTrainer:
-    def __init__(self, agent, engine, rollout_steps=128, minibatch=4096, value_chunk=16384):
+    def __init__(self, agent, engine, rollout_steps=128, minibatch=4096, value_chunk=16384, frame_codes=False):
+        """frame_codes=True stores the rollout's frames as uint8 codes (TW_F_MATRIX_CODE; 304 B instead of 1168 B
+        per env-step) and expands them to the same fp32 policy inputs when stacks are gathered: bit-identical
+        training, 3.8x less frame memory (BASELINE config 5)."""
         self.agent, self.engine = agent, engine
         self.T, self.N = int(rollout_steps), engine.num_envs
         self.minibatch, self.value_chunk = int(minibatch), int(value_chunk)
         d = self.device = engine.device
         T, N = self.T, self.N
-        self.frames_buf = torch.zeros((T + 4, N, 292), dtype=torch.float32, device=d)
+        self.frame_codes = bool(frame_codes)
+        if self.frame_codes:
+            self.frames_buf = torch.zeros((T + 4, N, 304), dtype=torch.uint8, device=d)
+        else:
+            self.frames_buf = torch.zeros((T + 4, N, 292), dtype=torch.float32, device=d)
         self.frames = self.frames_buf[..., :289]
         self.pos = torch.zeros((T + 4, N, 2), dtype=torch.float32, device=d)
         self.action = torch.zeros((T, N), dtype=torch.int32, device=d)
@@ -36,12 +43,21 @@ class VecPPOTrainer:
         self.init_pos = torch.tensor(INIT_POS, device=d)
         # the reset frame is a constant of the task: take it from a scratch engine step-free reset
         self.init_frame = self._reset_frame()
-        self.frames[:4] = self.init_frame
+        self.frames[:4] = self._encode(self.init_frame) if self.frame_codes else self.init_frame
         self.pos[:4] = self.init_pos
         agent.to(d)
         self.env_steps = 0
         self.episodes_done = 0
         self.return_sum = 0.0
+
+    @staticmethod
+    def _encode(frame):
+        """float matrix -> codes (0 free/goal 0.9, 1 wall -0.9, 2 ball -0.5, 3 agent 0.3)."""
+        c = torch.zeros_like(frame, dtype=torch.uint8)
+        c[frame == -0.9] = 1
+        c[frame == -0.5] = 2
+        c[frame == 0.3] = 3
+        return c
 
     def _reset_frame(self):
         ty, _, rec = self.engine.get_state()

@@ -39,6 +39,7 @@ def build_parser():
     p.add_argument("--rollout_steps", type=int, default=128)
     p.add_argument("--minibatch", type=int, default=4096)
     p.add_argument("--updates", type=int, default=1)
+    p.add_argument("--frame_codes", action="store_true", help="store rollout frames as uint8 codes (4x smaller, exact)")
     p.add_argument("--k_epochs", type=int, default=10)
     p.add_argument("--gae_lambda", type=float, default=0.0)
     p.add_argument("--normalize_adv", action="store_true")
@@ -59,7 +60,7 @@ def main(argv=None, predictor=False):
     random.seed(seed); np.random.seed(seed); os.environ["PYTHONHASHSEED"] = str(seed)
     if seed is not None:
         torch.manual_seed(seed); torch.cuda.manual_seed_all(seed)
-    device = torch.device("cuda", local_rank) if world > 1 else torch.device(args.cuda)
+    device = torch.device("cuda", local_rank % max(1, torch.cuda.device_count())) if world > 1 else torch.device(args.cuda)
     torch.cuda.set_device(device)
 
     if predictor:
@@ -82,7 +83,7 @@ def main(argv=None, predictor=False):
     lo, hi = twdist.shard_range(args.num_envs, rank, world)
     variant = 4 if args.env.endswith("v4") else 6
     engine = TwoarmyEngine(variant, hi - lo, 17, device=device, seed=seed or 0, env_id0=lo)
-    trainer = VecPPOTrainer(agent, engine, args.rollout_steps, args.minibatch)
+    trainer = VecPPOTrainer(agent, engine, args.rollout_steps, args.minibatch, frame_codes=args.frame_codes)
     for u in range(args.updates):
         t0 = time.perf_counter()
         trainer.collect()

@@ -39,6 +39,10 @@ extern "C" {
                                  (soa/train_ppo.py:104: every episode starts with reset()) */
 #define TW_F_POLICY_IDX 2     /* actions are policy indices 0..4; 4 -> done(6)
                                  (soa/env_buffer.py:364-376 Env_transact.env_action) */
+#define TW_F_MATRIX_CODE 4    /* reduced-precision frames (BASELINE config 5): `state_matrix` points to uint8 codes
+                                 [N][mat_pitch BYTES] (native pitch 304) -- 0 free/goal (0.9), 1 wall (-0.9), 2 ball (-0.5),
+                                 3 agent (0.3) -- instead of float[289]; exact (the matrix is a 4-entry LUT) and 4x smaller.
+                                 ppo_gather_stack_u8 expands it back to fp32 policy inputs. */
 
 /* per-env scalar record, int32 words (AoS: one 192-byte record per env) */
 enum tw_field {

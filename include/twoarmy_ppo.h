@@ -68,6 +68,13 @@ int ppo_gather_stack(const float *frames, int frame_pitch, const float *pos_fram
                      const int32_t *k_idx, const int32_t *n_idx, const int32_t *age, const float *init_frame,
                      const float *init_pos, int B, float *out, float *pos_out, void *stream);
 
+/* Same, for frames stored as uint8 codes (tw_step/tw_rollout with TW_F_MATRIX_CODE, twoarmy.h): frame_pitch in
+ * bytes, each code expanded to its matrix_env value {0: 0.9, 1: -0.9, 2: -0.5, 3: 0.3}; init_frame stays float[289].
+ * BASELINE config 5 ("reduced-precision frames"): the stored rollout is 4x smaller and the expansion is exact. */
+int ppo_gather_stack_u8(const uint8_t *frames, int frame_pitch, const float *pos_frames, int N,
+                        const int32_t *k_idx, const int32_t *n_idx, const int32_t *age, const float *init_frame,
+                        const float *init_pos, int B, float *out, float *pos_out, void *stream);
+
 /* Episode age before every step of a rollout: age[0][n] = age0[n]; age[t+1][n] = done[t][n] ? 0 : age[t][n]+1.
  *   done uint8[T][N] (terminated | truncated), age0 int32[N], age int32[T+1][N] */
 int ppo_age_scan(const uint8_t *terminated, const uint8_t *truncated, const int32_t *age0, int T, int N,

@@ -116,15 +116,18 @@ def _oracle(variant, N, T, view, env0):
     return _REF_CACHE[key]
 
 
+CODE_VALUES = np.array([0.9, -0.9, -0.5, 0.3], np.float32)
+
+
 def _compare_rollout(variant, N, T, view, env0=0, chunk=None, dense=False, epw=0, supply_actions=False,
-                     pipeline=True):
+                     pipeline=True, codes=False):
     """supply_actions=True feeds the (identical) Philox action stream through HBM, which makes the launch
     eligible for the pipelined kernel (logic wave + emission waves); otherwise the sequential kernel runs."""
     eng = _engine(variant, N, view, seed=SEED, env_id0=env0)
     eng.set_envs_per_wave(epw)
     eng.set_pipeline(pipeline)
     ref = _oracle(variant, N, T, view, env0)
-    out = eng.alloc_outputs(T, dense=dense)
+    out = eng.alloc_outputs(T, dense=dense, matrix_codes=codes)
     acts = eng.fill_actions(T) if supply_actions else None
     if chunk is None:
         eng.rollout(T, out, actions=acts)
@@ -136,6 +139,9 @@ def _compare_rollout(variant, N, T, view, env0=0, chunk=None, dense=False, epw=0
     torch.cuda.synchronize()
     for k in ("obs", "matrix", "pos", "reward", "terminated", "truncated"):
         got = out[k].cpu().numpy()
+        if codes and k == "matrix":                  # uint8 code frames: exact LUT expansion == the float matrix
+            assert got.dtype == np.uint8 and int(got.max()) <= 3
+            got = CODE_VALUES[got]
         assert got.dtype == ref[k].dtype and got.shape == ref[k].shape, k
         if not np.array_equal(got, ref[k]):
             bad = np.argwhere(got != ref[k])[0]
@@ -152,6 +158,33 @@ def test_pipelined_rollout_vs_oracle(variant, N, T, view, env0, chunk):
     """The pipelined kernel (closed-form logic wave + 15 emission waves per 16 envs): bit-exact vs the CPU
     oracle, incl. ragged N, small views, chunked launches (state hand-over through the ping-pong buffers)."""
     _compare_rollout(variant, N, T, view, env0=env0, chunk=chunk, supply_actions=True, pipeline=True)
+
+
+@pytest.mark.parametrize("variant", [6, 4])
+@pytest.mark.parametrize("N,T,view,env0,chunk,dense,pipe", [
+    (4096, 200, 17, 0, None, False, True), (1000, 130, 17, 77, 40, False, True), (513, 100, 7, 0, 9, False, True),
+    (4096, 200, 17, 0, None, False, False), (777, 90, 17, 3, None, True, False), (65, 64, 3, 7, 16, True, True)])
+def test_matrix_code_frames_vs_oracle(variant, N, T, view, env0, chunk, dense, pipe):
+    """TW_F_MATRIX_CODE (BASELINE config 5, reduced-precision frames): the uint8 code plane, expanded through its
+    4-entry LUT, is bit-identical to the oracle's float matrix -- pipelined and sequential kernels, native
+    (304-byte pitch) and dense (289) layouts; every other output unchanged."""
+    _compare_rollout(variant, N, T, view, env0=env0, chunk=chunk, dense=dense, supply_actions=pipe, pipeline=pipe,
+                     codes=True)
+
+
+def test_matrix_code_step_api_and_pad():
+    eng = _engine(6, 130, 17, seed=SEED)
+    ref = _oracle(6, 130, 30, 17, 0)
+    out = eng.alloc_outputs(matrix_codes=True)
+    raw = out["matrix"]._base
+    assert raw.shape[-1] == 304 and raw.dtype == torch.uint8
+    acts = eng.fill_actions(30)
+    for t in range(30):
+        eng.step(acts[t], out, autoreset=True, policy_idx=True)
+        assert np.array_equal(eng.decode_matrix(out["matrix"]).cpu().numpy(), ref["matrix"][t]), t
+        assert np.array_equal(out["obs"].cpu().numpy(), ref["obs"][t]), t
+    assert int(raw[..., 289:].max()) == 0
+    eng.close()
 
 
 @pytest.mark.parametrize("variant", [6, 4])

@@ -105,6 +105,35 @@ def test_rollout_stacks_equal_reference_style_stacks():
     eng.close()
 
 
+def test_frame_codes_trainer_is_bit_identical():
+    """Storing the rollout as uint8 code frames (ppo_gather_stack_u8) changes nothing: same actions, same
+    stacks, same losses as the float-frame trainer."""
+    from twoarmy_amd.engine import TwoarmyEngine
+    from twoarmy_amd.soa.agent.PPO import PPO
+    from twoarmy_amd.soa.ppo_vec import VecPPOTrainer
+    N, T = 64, 40
+    res = []
+    for codes in (False, True):
+        torch.manual_seed(3)
+        eng = TwoarmyEngine(4, N, 17, seed=SEED)
+        agent = PPO()
+        agent.K_epochs = 1
+        tr = VecPPOTrainer(agent, eng, rollout_steps=T, minibatch=512, frame_codes=codes)
+        g = torch.Generator(device="cpu").manual_seed(5)
+        uni = torch.rand(T, N, generator=g).to(tr.device)
+        tr.collect(uniforms=uni)
+        idx = torch.arange(T * N, device=tr.device)
+        s1, p1 = tr._stacks(idx // N, idx % N, after=True)
+        perms = [torch.randperm(T * N, generator=g).to(tr.device)]
+        la, lv = tr.update(permutations=perms)
+        res.append((tr.action.clone(), s1.clone(), p1.clone(), float(la), float(lv)))
+        assert tr.frames.dtype == (torch.uint8 if codes else torch.float32)
+        eng.close()
+    a, b = res
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert abs(a[3] - b[3]) <= 1e-6 and abs(a[4] - b[4]) <= 1e-6       # identical inputs; conv backward may reorder sums
+
+
 def test_train_ppo_entry_point_smoke():
     from twoarmy_amd.soa import train_ppo
     tr = train_ppo.main(["--env", "MiniGrid-twoarmy-17x17-v4", "--num_envs", "64", "--rollout_steps", "16",

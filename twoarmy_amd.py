@@ -6,6 +6,7 @@ imported real module object, so there is exactly one module object per file unde
 import importlib
 import importlib.abc
 import importlib.machinery
+import importlib.util
 import sys
 
 REAL = "goal-conditioned-reinforcement-learning-with-environmental-and-policy-priors_amd"
@@ -22,13 +23,22 @@ class _AliasLoader(importlib.abc.Loader):
     def exec_module(self, module):
         pass
 
+    # runpy (`python -m twoarmy_amd.soa.train_ppo`) asks the loader for the code object
+    def get_code(self, fullname):
+        real = REAL + fullname[len(ALIAS):]
+        return importlib.util.find_spec(real).loader.get_code(real)
+
+    def is_package(self, fullname):
+        return hasattr(self._module, "__path__")
+
 
 class _AliasFinder(importlib.abc.MetaPathFinder):
     def find_spec(self, fullname, path=None, target=None):
         if not fullname.startswith(ALIAS + "."):
             return None
         real = importlib.import_module(REAL + fullname[len(ALIAS):])
-        return importlib.machinery.ModuleSpec(fullname, _AliasLoader(real), is_package=hasattr(real, "__path__"))
+        return importlib.machinery.ModuleSpec(fullname, _AliasLoader(real), origin=getattr(real, "__file__", None),
+                                              is_package=hasattr(real, "__path__"))
 
 
 if not any(isinstance(f, _AliasFinder) for f in sys.meta_path):
