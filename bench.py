@@ -46,17 +46,20 @@ def traffic_from_profile(variant, n_envs, rollout_t, view):
         return json.load(f)["traffic_bytes_per_launch"]
 
 
-def cpu_baseline(variant, n_envs, view, seconds=12.0):
-    """CPU oracle ("port": oracle/twoarmy_oracle.c, single thread) on a bounded sample of the same workload:
-    the same 4096 envs stepped with the same Philox action stream and auto-reset for ~12 s of CPU time."""
+def cpu_baseline(variant, n_envs, view, seconds=10.0):
+    """CPU oracle ("port": oracle/twoarmy_oracle.c) on a bounded sample of the same workload: the same 4096 envs
+    stepped with the same Philox action stream and auto-reset, sharded over every host core this process may use
+    (~10 s), plus a short single-thread run for the per-core figure."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import twoarmy_oracle as orc
     orc.lib()
-    steps, dt = orc.timed_rollout(variant, n_envs, seconds, SEED, view=view)
-    return {"value": steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": "%d envs x %d steps of the same workload (oracle/twoarmy_oracle.c, gcc -O2, 1 thread, %.1f s)"
-                      % (n_envs, steps // n_envs, dt),
-            "host_cores_available": os.cpu_count()}
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    steps1, dt1 = orc.timed_rollout(variant, n_envs, 4.0, SEED, view=view, threads=1)
+    steps, dt = orc.timed_rollout(variant, n_envs, seconds, SEED, view=view, threads=cores)
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d envs x %d steps of the same workload (oracle/twoarmy_oracle.c, gcc -O2, %d threads, %.1f s)"
+                      % (n_envs, steps // n_envs, cores, dt),
+            "single_thread_value": steps1 / dt1, "host_cores_available": os.cpu_count()}
 
 
 def main():
@@ -135,6 +138,17 @@ def main():
     achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
     traffic = None if args.matrix_codes else traffic_from_profile(args.variant, N, T, V)
     torch.cuda.synchronize()
+    # write-only ceiling of this very box (report a measured device ceiling beside the vendor peak)
+    buf = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    buf.fill_(1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        buf.fill_(2)
+    e1.record()
+    torch.cuda.synchronize()
+    fill_gbs = 5 * buf.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del buf
 
     if rank == 0:
         res = {
@@ -156,7 +170,9 @@ def main():
                                            if traffic is not None else None,
                          "kernel": "tw_pipe_kernel (+ flag-gated tw_rollout_kernel fallback launch)" if T >= 8 and os.environ.get("TW_PIPELINE", "1") != "0" else "tw_rollout_kernel", "kernel_ms": k_ms, "launches_timed": iters,
                          "algorithmic_bytes_per_env_step": bpe, "bytes_per_launch": bytes_per_launch,
-                         "survey_bytes_per_env_step": 2690, "us_per_env_batch_step": k_ms * 1e3 / T},
+                         "survey_bytes_per_env_step": 2690, "us_per_env_batch_step": k_ms * 1e3 / T,
+                         "launches_per_env_batch_step": 2.0 / T, "measured_fill_ceiling_GBs": fill_gbs,
+                         "frac_of_measured_fill_ceiling": achieved / fill_gbs},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(variant, N, V)

@@ -118,28 +118,53 @@ class OracleEnv:
                     ball_x=tuple(e.ob_x), ball_y=tuple(e.ob_y))
 
 
-def timed_rollout(variant, N, seconds, seed, view=17, chunk=64):
+def timed_rollout(variant, N, seconds, seed, view=17, chunk=64, threads=1):
     """CPU baseline leg of bench.py: keep stepping the same N envs (state carried across chunks, outputs
-    written to reused [chunk,N,...] buffers) for about `seconds`; returns (env_steps, elapsed_seconds)."""
+    written to reused [chunk,n,...] buffers) for about `seconds`; returns (env_steps, elapsed_seconds).
+    threads > 1 shards the envs over that many host threads (ctypes releases the GIL during the C call),
+    each with its own env range [env0, env0+n) and its own output buffers."""
+    import threading
     import time
-    envs = (TwEnv * N)()
-    for n in range(N):
-        lib().tw_oracle_init(C.byref(envs[n]), variant)
-    obs = np.empty((chunk, N, view, view, 3), np.uint8)
-    mat = np.empty((chunk, N, NC), np.float32)
-    pos = np.empty((chunk, N, 2), np.float32)
-    rew = np.empty((chunk, N), np.float32)
-    te = np.empty((chunk, N), np.uint8)
-    tr = np.empty((chunk, N), np.uint8)
-    steps = 0
-    t0 = time.perf_counter()
-    while True:
-        lib().tw_oracle_rollout(variant, N, chunk, seed, 0, view, None, C.cast(envs, C.c_void_p), _ptr(obs), _ptr(mat),
-                                _ptr(pos), _ptr(rew), _ptr(te), _ptr(tr), 1)
-        steps += N * chunk
-        dt = time.perf_counter() - t0
-        if dt >= seconds:
-            return steps, dt
+    lib()
+    threads = max(1, min(int(threads), N))
+    bounds = [N * k // threads for k in range(threads + 1)]
+    counts = [0] * threads
+    start = threading.Barrier(threads)
+    t0 = [0.0]
+
+    def work(k):
+        e0, n = bounds[k], bounds[k + 1] - bounds[k]
+        envs = (TwEnv * n)()
+        for i in range(n):
+            lib().tw_oracle_init(C.byref(envs[i]), variant)
+        obs = np.empty((chunk, n, view, view, 3), np.uint8)
+        mat = np.empty((chunk, n, NC), np.float32)
+        pos = np.empty((chunk, n, 2), np.float32)
+        rew = np.empty((chunk, n), np.float32)
+        te = np.empty((chunk, n), np.uint8)
+        tr = np.empty((chunk, n), np.uint8)
+        def go():
+            lib().tw_oracle_rollout(variant, n, chunk, seed, e0, view, None, C.cast(envs, C.c_void_p), _ptr(obs),
+                                    _ptr(mat), _ptr(pos), _ptr(rew), _ptr(te), _ptr(tr), 1)
+        go()                                   # untimed: first touch of the output pages
+        if start.wait() == 0:
+            t0[0] = time.perf_counter()
+        start.wait()
+        while True:
+            go()
+            counts[k] += n * chunk
+            if time.perf_counter() - t0[0] >= seconds:
+                return
+
+    if threads == 1:
+        work(0)
+    else:
+        ts = [threading.Thread(target=work, args=(k,)) for k in range(threads)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    return sum(counts), time.perf_counter() - t0[0]
 
 
 def rollout(variant, N, T, seed, env0=0, view=17, actions=None, autoreset=True,
