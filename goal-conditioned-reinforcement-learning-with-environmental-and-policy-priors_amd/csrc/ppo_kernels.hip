@@ -269,6 +269,96 @@ __global__ __launch_bounds__(64) void ppo_gather_stack_kernel(const FT *__restri
     }
 }
 
+// ------------------------------------------------------------------ hindsight relabelling (HER)
+// Buffer_gridworld.her_func (soa/env_buffer.py:101-143) over a time-major rollout.  The reference copies
+// episode prefixes into its ring buffer; here a relabelled transition is only an index record
+// (t, n, goal', reward', done'): the frames / positions / action / old log-prob are those of (t, n).
+// One wavefront per env walks its episodes in time order; an episode (<= 64 steps) sits one step per lane.
+constexpr int HER_MAX_LEN = 64;
+
+__global__ __launch_bounds__(64) void ppo_her_kernel(const float *__restrict__ pos, const uint8_t *__restrict__ terminated,
+                                                     const uint8_t *__restrict__ truncated,
+                                                     const int32_t *__restrict__ age0, const float *__restrict__ reward,
+                                                     const int32_t *__restrict__ choices, uint32_t k0, uint32_t k1,
+                                                     uint32_t env_id0, uint32_t step0, int T, int N, int max_goals,
+                                                     const int64_t *__restrict__ offsets, int32_t *__restrict__ counts,
+                                                     int32_t *__restrict__ out_t, int32_t *__restrict__ out_n,
+                                                     float *__restrict__ out_goal, float *__restrict__ out_reward,
+                                                     uint8_t *__restrict__ out_done) {
+    const int n = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (n >= N) return;
+    const bool emit = offsets != nullptr;
+    int64_t base = emit ? offsets[n] : 0;
+    int total = 0;
+    int start = age0[n] == 0 ? 0 : -1;               // an episode already running at t = 0 is not relabelled
+    for (int c0 = 0; c0 < T; c0 += 64) {
+        const int tl = c0 + lane;
+        const bool d = tl < T && (terminated[(size_t)tl * N + n] | truncated[(size_t)tl * N + n]) != 0;
+        unsigned long long dm = __ballot(d);
+        while (dm) {
+            const int t1 = c0 + __builtin_ctzll(dm);
+            dm &= dm - 1;
+            const int s0 = start;
+            start = t1 + 1;
+            if (s0 < 0) continue;
+            const int L = t1 - s0 + 1;
+            if (L > HER_MAX_LEN) continue;
+            // lane i = record i of the episode: achieved (y, x) after step s0 + i
+            const bool in = lane < L;
+            const size_t row = (size_t)(s0 + (in ? lane : 0)) * N + n;
+            const float py = pos[row * 2], px = pos[row * 2 + 1];
+            // np.unique(axis=0): first occurrence of every distinct (y, x), ordered lexicographically by (y, x)
+            bool first = in;
+            for (int j = 0; j < L; ++j) {
+                const float qy = __shfl(py, j), qx = __shfl(px, j);
+                if (j < lane && qy == py && qx == px) first = false;
+            }
+            const unsigned long long fm = __ballot(first);
+            const int U = __popcll(fm);
+            int rank = 0;
+            for (int j = 0; j < L; ++j) {
+                const float qy = __shfl(py, j), qx = __shfl(px, j);
+                if (((fm >> j) & 1ull) && (qy < py || (qy == py && qx < px))) ++rank;
+            }
+            const int k = max_goals < U ? max_goals : U;
+            // Fisher-Yates over the U unique entries when no explicit picks are supplied (lane j holds perm[j])
+            int perm = lane;
+            if (!choices) {
+                uint32_t w0 = env_id0 + (uint32_t)n, w1 = step0 + (uint32_t)t1, w2 = 0, w3 = 0x54574F48u;   // 'TWOH'
+                philox4x32_10(k0, k1, w0, w1, w2, w3);
+                const uint32_t w[4] = {w0, w1, w2, w3};
+                for (int j = 0; j < k && j < 4; ++j) {
+                    const int sidx = j + (int)(w[j] % (uint32_t)(U - j));
+                    const int pj = __shfl(perm, j), ps = __shfl(perm, sidx);
+                    if (lane == j) perm = ps;
+                    else if (lane == sidx) perm = pj;
+                }
+            }
+            for (int j = 0; j < k; ++j) {
+                const int pick = choices ? choices[((size_t)t1 * N + n) * 4 + j] : __shfl(perm, j);
+                if (pick < 0 || pick >= U) continue;
+                const unsigned long long hit = __ballot(first && rank == pick);
+                if (!hit) continue;
+                const int idx = __builtin_ctzll(hit);
+                if (idx == 0) continue;                                  // env_buffer.py:119 `if 0 < index < cap`
+                if (emit && lane <= idx) {
+                    const int64_t o = base + lane;
+                    out_t[o] = s0 + lane;
+                    out_n[o] = n;
+                    out_goal[o * 2] = __shfl(py, idx);
+                    out_goal[o * 2 + 1] = __shfl(px, idx);
+                    out_reward[o] = lane == idx ? 0.9f : reward[row];
+                    out_done[o] = lane == idx ? 1 : 0;
+                }
+                base += idx + 1;
+                total += idx + 1;
+            }
+        }
+    }
+    if (lane == 0 && counts) counts[n] = total;
+}
+
 __global__ void ppo_age_scan_kernel(const uint8_t *__restrict__ terminated, const uint8_t *__restrict__ truncated,
                                     const int32_t *__restrict__ age0, int T, int N, int32_t *__restrict__ age) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -357,6 +447,20 @@ int ppo_gather_stack_u8(const uint8_t *frames, int frame_pitch, const float *pos
     if (pos_out && (!pos_frames || !init_pos)) return TW_E_ARG;
     hipLaunchKernelGGL(ppo_gather_stack_kernel<uint8_t>, dim3(B * 4), dim3(64), 0, (hipStream_t)stream, frames,
                        frame_pitch, pos_frames, N, k_idx, n_idx, age, init_frame, init_pos, B, out, pos_out);
+    return check_launch();
+}
+
+int ppo_her_relabel(const float *pos, const uint8_t *terminated, const uint8_t *truncated, const int32_t *age0,
+                    const float *reward, const int32_t *choices, uint64_t seed, uint32_t env_id0, uint32_t step0, int T,
+                    int N, int max_goals, const int64_t *offsets, int32_t *counts, int32_t *out_t, int32_t *out_n,
+                    float *out_goal, float *out_reward, uint8_t *out_done, void *stream) {
+    if (!pos || !terminated || !truncated || !age0 || !reward || T <= 0 || N <= 0 || max_goals < 0) return TW_E_ARG;
+    if (max_goals > 4) return TW_E_ARG;                                  // 4 pick columns / one Philox call
+    if (!offsets && !counts) return TW_E_ARG;
+    if (offsets && (!out_t || !out_n || !out_goal || !out_reward || !out_done)) return TW_E_ARG;
+    hipLaunchKernelGGL(ppo_her_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, pos, terminated, truncated, age0,
+                       reward, choices, (uint32_t)seed, (uint32_t)(seed >> 32), env_id0, step0, T, N, max_goals, offsets,
+                       counts, out_t, out_n, out_goal, out_reward, out_done);
     return check_launch();
 }
 

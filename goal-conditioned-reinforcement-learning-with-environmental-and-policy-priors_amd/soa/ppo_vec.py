@@ -46,6 +46,8 @@ class VecPPOTrainer:
         self.frames[:4] = self._encode(self.init_frame) if self.frame_codes else self.init_frame
         self.pos[:4] = self.init_pos
         agent.to(d)
+        self.her = None                       # relabelled index records of the current rollout (relabel())
+        self.her_seed = int(getattr(engine, "seed", 9981))
         self.env_steps = 0
         self.episodes_done = 0
         self.return_sum = 0.0
@@ -98,26 +100,54 @@ class VecPPOTrainer:
         return ppo_ops.gather_stack(self.frames, self.pos, k.int(), n_idx.int(), age.int(), self.init_frame,
                                     self.init_pos)
 
+    # ------------------------------------------------------------------ hindsight relabelling
+    @torch.no_grad()
+    def relabel(self, choices=None, max_goals=4):
+        """Buffer_gridworld.her_func (env_buffer.py:101-143) for every episode that lies inside this rollout:
+        relabelled transitions are index records (t, n, goal', reward', done') produced on the device
+        (ppo_her_relabel); update() then trains on the rollout plus these records, like the reference trains on
+        its ring buffer with the appended copies."""
+        T = self.T
+        self.her = ppo_ops.her_relabel(self.pos[4:4 + T], self.term, self.trunc, self.age[0].contiguous(), self.reward,
+                                       choices, seed=self.her_seed, env_id0=self.engine.env_id0,
+                                       step0=self.env_steps // self.N, max_goals=max_goals)
+        return self.her
+
+    def _values(self, t_idx, n_idx, goal):
+        """critic(s, g) and critic(s', g) of samples (t, n) with per-sample goals, in chunks."""
+        total = t_idx.numel()
+        v = torch.empty(total, device=self.device)
+        nv = torch.empty(total, device=self.device)
+        self.agent.critic.eval()
+        for i in range(0, total, self.value_chunk):
+            sl = slice(i, min(total, i + self.value_chunk))
+            s0, p0 = self._stacks(t_idx[sl], n_idx[sl], after=False)
+            v[sl] = self.agent.critic(self.agent.policy_input(s0), p0, goal[sl]).view(-1)
+            s1, p1 = self._stacks(t_idx[sl], n_idx[sl], after=True)
+            nv[sl] = self.agent.critic(self.agent.policy_input(s1), p1, goal[sl]).view(-1)
+        return v, nv
+
     @torch.no_grad()
     def compute_targets(self):
         T, N = self.T, self.N
         total = T * N
-        v = torch.empty(total, device=self.device)
-        nv = torch.empty(total, device=self.device)
         idx = torch.arange(total, device=self.device)
-        self.agent.critic.eval()
-        for i in range(0, total, self.value_chunk):
-            sl = idx[i:i + self.value_chunk]
-            t_idx, n_idx = sl // N, sl % N
-            g = self.goal1.expand(sl.numel(), 2)
-            s0, p0 = self._stacks(t_idx, n_idx, after=False)
-            v[i:i + sl.numel()] = self.agent.critic(self.agent.policy_input(s0), p0, g).view(-1)
-            s1, p1 = self._stacks(t_idx, n_idx, after=True)
-            nv[i:i + sl.numel()] = self.agent.critic(self.agent.policy_input(s1), p1, g).view(-1)
+        v, nv = self._values(idx // N, idx % N, self.goal1.expand(total, 2))
         done = (self.term | self.trunc).contiguous()
         adv, target, ret = ppo_ops.gae(self.reward, v.view(T, N), nv.view(T, N), done, gamma=self.agent.gamma,
                                        lam=self.agent.gae_lambda, use_done_mask=self.agent.use_done_mask)
         critic_target = target if self.agent.gae_lambda == 0.0 else ret
+        adv, critic_target = adv.view(-1), critic_target.view(-1)
+        if self.her is not None and self.her["t"].numel():
+            # relabelled records: the reference's one-step target with the relabelled goal and reward (PPO.py:112-114)
+            assert self.agent.gae_lambda == 0.0 and not self.agent.use_done_mask, "HER records use the TD(0) targets"
+            h = self.her
+            hv, hnv = self._values(h["t"], h["n"], h["goal"])
+            H = hv.numel()
+            hadv, htarget, _ = ppo_ops.gae(h["reward"].view(1, H), hv.view(1, H), hnv.view(1, H), None,
+                                           gamma=self.agent.gamma, lam=0.0, use_done_mask=False)
+            adv = torch.cat([adv, hadv.view(-1)])
+            critic_target = torch.cat([critic_target, htarget.view(-1)])
         if self.agent.normalize_adv:
             ppo_ops.adv_norm_(adv)
         return adv, critic_target
@@ -125,23 +155,53 @@ class VecPPOTrainer:
     def update(self, permutations=None):
         ag = self.agent
         T, N = self.T, self.N
-        total = T * N
         adv, target = self.compute_targets()
-        adv, target = adv.view(-1), target.view(-1)
-        act, logp = self.action.view(-1), self.logp.view(-1)
+        total = adv.numel()                                           # rollout samples + relabelled records
+        base = torch.arange(T * N, device=self.device)
+        smp_t, smp_n = (base // N).int(), (base % N).int()
+        smp_goal = self.goal1.expand(T * N, 2)
+        if total > T * N:
+            smp_t = torch.cat([smp_t, self.her["t"]])
+            smp_n = torch.cat([smp_n, self.her["n"]])
+            smp_goal = torch.cat([smp_goal, self.her["goal"]])
+        flat = smp_t.long() * N + smp_n.long()                        # action / old log-prob are those of (t, n)
+        act, logp = self.action.view(-1)[flat], self.logp.view(-1)[flat]
         ag.actor.train(); ag.critic.train()
         la = lv = None
+        local_steps = n_steps = -(-total // self.minibatch)
+        if ag.grad_sync is not None and torch.distributed.is_initialized():
+            # relabelled-record counts differ per rank; every rank must take part in the same number of all-reduces
+            m = torch.tensor([n_steps], device=self.device)
+            torch.distributed.all_reduce(m, op=torch.distributed.ReduceOp.MAX)
+            n_steps = int(m.item())
         for ep in range(ag.K_epochs):
             perm = (torch.randperm(total) if permutations is None else torch.as_tensor(permutations[ep])).to(self.device)
-            for i in range(0, total, self.minibatch):
+            if n_steps > local_steps:                  # a rank with fewer records revisits samples of this epoch
+                perm = torch.cat([perm, perm.repeat(n_steps // local_steps + 1)])[:n_steps * self.minibatch]
+            for i in range(0, perm.numel(), self.minibatch):
                 idx = perm[i:i + self.minibatch]
-                t_idx, n_idx = idx // N, idx % N
-                s0, p0 = self._stacks(t_idx, n_idx, after=False)
-                la, lv = ag.minibatch_step(s0, p0, self.goal1.expand(idx.numel(), 2), act[idx], logp[idx].view(-1, 1),
+                s0, p0 = self._stacks(smp_t[idx], smp_n[idx], after=False)
+                la, lv = ag.minibatch_step(s0, p0, smp_goal[idx], act[idx], logp[idx].view(-1, 1),
                                            adv[idx].view(-1, 1), target[idx].view(-1, 1))
         if ag.use_lr_decay:
             ag.scheduler_actor.step(); ag.scheduler_critic.step()
+        self.her = None
         return la, lv
+
+    def her_switch(self, her, score):
+        """The reference's hysteresis (train_ppo.py:128-131): relabelling off above 0.1, on again below 0."""
+        return False if score > 0.1 else (True if score < 0.0 else her)
+
+    def running_score(self, score):
+        """EMA of episode returns (train_ppo.py:140: score <- 0.99 score + 0.01 ep_reward per finished episode),
+        applied once per rollout with the mean return of the E episodes that ended in it."""
+        done = (self.term | self.trunc) != 0
+        E = int(done.sum())
+        if E == 0:
+            return score
+        mean_ret = float(self.reward.sum()) / E
+        k = 0.99 ** E
+        return score * k + mean_ret * (1.0 - k)
 
     def stats(self):
         done = (self.term | self.trunc) != 0

@@ -84,11 +84,18 @@ def main(argv=None, predictor=False):
     variant = 4 if args.env.endswith("v4") else 6
     engine = TwoarmyEngine(variant, hi - lo, 17, device=device, seed=seed or 0, env_id0=lo)
     trainer = VecPPOTrainer(agent, engine, args.rollout_steps, args.minibatch, frame_codes=args.frame_codes)
+    her = str(args.her).lower() not in ("false", "0", "no")
+    score = 0.0
     for u in range(args.updates):
         t0 = time.perf_counter()
         trainer.collect()
+        her = trainer.her_switch(her, score)                  # train_ppo.py:128-131 of the reference
+        if her and agent.gae_lambda == 0.0:
+            trainer.relabel()
+        score = trainer.running_score(score)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
+        n_her = 0 if trainer.her is None else int(trainer.her["t"].numel())
         la, lv = trainer.update()
         torch.cuda.synchronize()
         t2 = time.perf_counter()
@@ -96,9 +103,9 @@ def main(argv=None, predictor=False):
         trainer.carry_over()
         if rank == 0:
             print("update %d: rollout %.3fs (%.0f env-steps/s/rank) update %.3fs action_loss %.5f value_loss %.5f "
-                  "episodes %d successes %d mean_r %.4f" % (u, t1 - t0, trainer.T * trainer.N / (t1 - t0), t2 - t1,
+                  "episodes %d successes %d mean_r %.4f her_records %d score %.4f" % (u, t1 - t0, trainer.T * trainer.N / (t1 - t0), t2 - t1,
                                                             float(la), float(lv), st["episodes"], st["successes"],
-                                                            st["mean_reward"]), flush=True)
+                                                            st["mean_reward"], n_her, score), flush=True)
     engine.close()
     return trainer
 

@@ -80,6 +80,31 @@ int ppo_gather_stack_u8(const uint8_t *frames, int frame_pitch, const float *pos
 int ppo_age_scan(const uint8_t *terminated, const uint8_t *truncated, const int32_t *age0, int T, int N,
                  int32_t *age, void *stream);
 
+/* Hindsight experience replay over one time-major rollout: replaces Buffer_gridworld.her_func
+ * (soa/env_buffer.py:101-143, called from soa/train_ppo.py:128-134 at every episode end).  For every episode
+ * [s0, t1] that starts (age0[n] == 0 or the step after a done) and ends (terminated | truncated) inside the
+ * rollout and has <= 64 records:
+ *   first_visit = np.unique(achieved (y,x) of its records, axis=0, return_index=True)   (lexicographic order)
+ *   k = min(max_goals, len(first_visit)); picks = k entries of first_visit without replacement
+ *   for index in picks (in pick order), skipping index == 0:  records 0..index are relabelled with
+ *       goal := achieved(index), reward[index] := 0.9, done[index] := 1           (env_buffer.py:120-125)
+ * The reference appends copies of those records to its ring buffer; here a relabelled record is the index tuple
+ * (t, n, goal, reward, done) -- frames, positions, action and old log-prob are those of (t, n), which the
+ * reference copies unchanged.  Output order: env-major, episodes in time order, picks in pick order, prefix in
+ * time order (deterministic).
+ *   choices int32[T][N][4] | NULL: row (t1, n) holds the picks of the episode ending at t1 as positions in the
+ *       sorted unique array (entries outside [0, U) are ignored) -- replays any external RNG, e.g. the global
+ *       np.random.choice stream of the reference.  NULL: partial Fisher-Yates with the words of
+ *       Philox4x32-10(key = seed, counter = (env_id0 + n, step0 + t1, 0, 'TWOH')), pick j swaps perm[j] with
+ *       perm[j + word_j % (U - j)]  (max_goals <= 4).
+ * Two passes: offsets == NULL -> only counts[n] (records produced by env n) is written; then, with
+ * offsets = exclusive prefix sum of counts (int64[N]), the records are written at offsets[n] ....
+ *   pos float[T][N][2] (achieved (y,x) after each step), reward float[T][N], age0 int32[N] (episode age at t=0) */
+int ppo_her_relabel(const float *pos, const uint8_t *terminated, const uint8_t *truncated, const int32_t *age0,
+                    const float *reward, const int32_t *choices, uint64_t seed, uint32_t env_id0, uint32_t step0, int T,
+                    int N, int max_goals, const int64_t *offsets, int32_t *counts, int32_t *out_t, int32_t *out_n,
+                    float *out_goal, float *out_reward, uint8_t *out_done, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

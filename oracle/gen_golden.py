@@ -314,6 +314,7 @@ def collect_buffer(env_buffer, variant, n_records, seed):
         def show_img(self, *_):
             pass
     t = 0
+    buf.episode_ends = []                   # index of the last record of every finished episode (harness bookkeeping)
     with rh.patched_choice(rec):
         env = rh.make_env(variant)
         while not buf.full:
@@ -333,6 +334,8 @@ def collect_buffer(env_buffer, variant, n_records, seed):
                            np.array(st_stack, dtype='float32'), np.array(goal, dtype='float32'),
                            np.array([r], dtype='float32'), np.array([done], dtype='int64'),
                            np.array([logp], dtype='float32')))
+                if term or trunc:
+                    buf.episode_ends.append((buf.counter - 1) % n_records)
                 if term or trunc or buf.full:
                     break
     return buf
@@ -402,17 +405,17 @@ def gen_her():
     """Buffer_gridworld.her_func (soa/env_buffer.py:101-143) on recorded episodes, incl. ring wrap."""
     env_buffer, _ = rh.soa_modules()
     out = {}
-    cases = [dict(cap=64, seed=0, pre=0), dict(cap=64, seed=1, pre=17), dict(cap=40, seed=2, pre=25),
-             dict(cap=48, seed=5, pre=30), dict(cap=64, seed=7, pre=3)]
+    cases = [dict(cap=256, seed=0, pre=0, ep=0, variant="v6"), dict(cap=256, seed=1, pre=17, ep=1, variant="v6"),
+             dict(cap=70, seed=2, pre=25, ep=0, variant="v6"), dict(cap=96, seed=5, pre=30, ep=2, variant="v4"),
+             dict(cap=128, seed=7, pre=3, ep=1, variant="v4"), dict(cap=60, seed=11, pre=8, ep=0, variant="v4"),
+             dict(cap=200, seed=13, pre=100, ep=3, variant="v6")]
     for ci, c in enumerate(cases):
-        buf = collect_buffer(env_buffer, "v6", 256, seed=10 + ci)     # source of realistic records
+        buf = collect_buffer(env_buffer, c["variant"], 256, seed=10 + ci)     # source of realistic records
         src = buf.buffer
-        # one full episode = records from index 0 to the first done/truncation boundary (p stack restarts)
-        # find episode end: next record whose stack is 5 identical positions shifted once
-        L = 1
-        while L < 60 and not (src['p'][L][0] == src['p'][L][1]).all():
-            L += 1
-        ep = src[:L].copy()
+        ends = buf.episode_ends
+        first = 0 if c["ep"] == 0 else ends[c["ep"] - 1] + 1
+        L = ends[c["ep"]] - first + 1
+        ep = src[first:first + L].copy()
         b2 = env_buffer.Buffer_gridworld()
         b2.grid_size = 17
         b2.transition = src.dtype

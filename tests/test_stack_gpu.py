@@ -134,6 +134,43 @@ def test_frame_codes_trainer_is_bit_identical():
     assert abs(a[3] - b[3]) <= 1e-6 and abs(a[4] - b[4]) <= 1e-6       # identical inputs; conv backward may reorder sums
 
 
+def test_trainer_with_device_her_records():
+    """relabel() + update(): the relabelled index records extend the sample set; their TD(0) targets use the
+    relabelled goal and reward (checked against a direct torch evaluation of PPO.py:112-114)."""
+    from twoarmy_amd.engine import TwoarmyEngine
+    from twoarmy_amd.soa.agent.PPO import PPO
+    from twoarmy_amd.soa.ppo_vec import VecPPOTrainer
+    torch.manual_seed(1)
+    N, T = 96, 120
+    eng = TwoarmyEngine(4, N, 17, seed=SEED)
+    agent = PPO()
+    agent.K_epochs = 1
+    tr = VecPPOTrainer(agent, eng, rollout_steps=T, minibatch=2048)
+    tr.collect()
+    h = tr.relabel()
+    H = int(h["t"].numel())
+    assert H > 0 and int(h["counts"].sum()) == H
+    # every record points at a real (t, n) of an episode and carries an achieved position of that episode as goal
+    t, n = h["t"].long(), h["n"].long()
+    ends = torch.nonzero(h["done"]).view(-1)
+    assert bool((h["reward"][ends] == 0.9).all())
+    assert bool((tr.pos[4:][t[ends], n[ends]] == h["goal"][ends]).all())
+    adv, target = tr.compute_targets()
+    assert adv.numel() == T * N + H
+    with torch.no_grad():
+        s0, p0 = tr._stacks(h["t"], h["n"], after=False)
+        s1, p1 = tr._stacks(h["t"], h["n"], after=True)
+        agent.critic.eval()
+        v = agent.critic(agent.policy_input(s0), p0, h["goal"]).view(-1)
+        nv = agent.critic(agent.policy_input(s1), p1, h["goal"]).view(-1)
+        want_t = h["reward"] + agent.gamma * nv
+    assert torch.allclose(target[T * N:], want_t, atol=1e-5) and torch.allclose(adv[T * N:], want_t - v, atol=1e-5)
+    la, lv = tr.update()
+    assert np.isfinite(float(la)) and np.isfinite(float(lv)) and tr.her is None
+    assert tr.her_switch(True, 0.2) is False and tr.her_switch(False, -0.1) is True and tr.her_switch(False, 0.05) is False
+    eng.close()
+
+
 def test_train_ppo_entry_point_smoke():
     from twoarmy_amd.soa import train_ppo
     tr = train_ppo.main(["--env", "MiniGrid-twoarmy-17x17-v4", "--num_envs", "64", "--rollout_steps", "16",
