@@ -85,17 +85,33 @@ class PPO:
         self.use_done_mask = False
         self.normalize_adv = False
         self.grad_sync = None                      # callable(list_of_params) for multi-GPU (dist.py)
+        self.amp_dtype = None                      # torch.bfloat16: conv/linear GEMMs on bf16 MFMA (opt-in; fp32 = parity)
 
     # ------------------------------------------------------------------ acting
     def policy_input(self, frames4):
         """Hook: what the networks consume for a 4-frame stack (the predictor variant appends 4 predicted frames)."""
         return frames4
 
+    def _run(self, net, x, p, g):
+        """Network forward; under `amp_dtype` the conv/linear GEMMs run in that dtype (fp32 master weights, fp32
+        outputs and losses).  Default (None) is plain fp32, the only mode with a parity claim."""
+        if self.amp_dtype is None:
+            return net(x, p, g)
+        with torch.autocast(device_type="cuda", dtype=self.amp_dtype):
+            out = net(x, p, g)
+        return out.float()
+
+    def actor_probs(self, x, p, g):
+        return self._run(self.actor, x, p, g)
+
+    def critic_value(self, x, p, g):
+        return self._run(self.critic, x, p, g)
+
     @torch.no_grad()
     def act_batch(self, frames4, pos4, goal, uniforms=None):
         """frames4 [B,4,289], pos4 [B,4,2], goal [B,2] (device) -> (action int32[B], logp float[B])."""
         self.actor.eval()
-        probs = self.actor(self.policy_input(frames4), pos4, goal)
+        probs = self.actor_probs(self.policy_input(frames4), pos4, goal)
         a, logp = ppo_ops.sample(probs, uniforms, seed=self.sample_seed, offset=self.sample_count)
         self.sample_count += probs.shape[0]
         return a, logp
@@ -122,8 +138,8 @@ class PPO:
         nv = torch.empty(n, device=s.device)
         for i in range(0, n, chunk):
             j = min(n, i + chunk)
-            nv[i:j] = self.critic(self.policy_input(s[i:j, 1:5]), p[i:j, 1:5], g[i:j]).view(-1)
-            v[i:j] = self.critic(self.policy_input(s[i:j, 0:4]), p[i:j, 0:4], g[i:j]).view(-1)
+            nv[i:j] = self.critic_value(self.policy_input(s[i:j, 1:5]), p[i:j, 1:5], g[i:j]).view(-1)
+            v[i:j] = self.critic_value(self.policy_input(s[i:j, 0:4]), p[i:j, 0:4], g[i:j]).view(-1)
         adv, target, _ = ppo_ops.gae(r.view(1, n).contiguous(), v.view(1, n), nv.view(1, n),
                                      None if done is None else done.view(1, n).contiguous(),
                                      gamma=self.gamma, lam=0.0, use_done_mask=False, want_ret=False)
@@ -132,8 +148,8 @@ class PPO:
     def minibatch_step(self, s0, p0, g, a, old_logp, adv, target_v):
         """One optimiser step on one minibatch (PPO.py:122-147); returns (action_loss, value_loss) tensors."""
         x0 = self.policy_input(s0)
-        probs = self.actor(x0, p0, g)
-        value = self.critic(x0, p0, g)
+        probs = self.actor_probs(x0, p0, g)
+        value = self.critic_value(x0, p0, g)
         action_loss, value_loss = ppo_ops.ppo_losses(probs, value, a, old_logp, adv, target_v,
                                                      clip=self.clip_param, ent_coef=self.entropy_coef)
         self.optimizer_actor.zero_grad()

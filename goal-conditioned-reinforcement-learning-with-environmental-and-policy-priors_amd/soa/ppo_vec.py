@@ -122,9 +122,9 @@ class VecPPOTrainer:
         for i in range(0, total, self.value_chunk):
             sl = slice(i, min(total, i + self.value_chunk))
             s0, p0 = self._stacks(t_idx[sl], n_idx[sl], after=False)
-            v[sl] = self.agent.critic(self.agent.policy_input(s0), p0, goal[sl]).view(-1)
+            v[sl] = self.agent.critic_value(self.agent.policy_input(s0), p0, goal[sl]).view(-1)
             s1, p1 = self._stacks(t_idx[sl], n_idx[sl], after=True)
-            nv[sl] = self.agent.critic(self.agent.policy_input(s1), p1, goal[sl]).view(-1)
+            nv[sl] = self.agent.critic_value(self.agent.policy_input(s1), p1, goal[sl]).view(-1)
         return v, nv
 
     @torch.no_grad()

@@ -39,6 +39,8 @@ def build_parser():
     p.add_argument("--rollout_steps", type=int, default=128)
     p.add_argument("--minibatch", type=int, default=4096)
     p.add_argument("--updates", type=int, default=1)
+    p.add_argument("--amp", default="fp32", choices=["fp32", "bf16"],
+                   help="GEMM dtype of the actor-critic (bf16 = torch.autocast, no parity claim; fp32 = reference)")
     p.add_argument("--frame_codes", action="store_true", help="store rollout frames as uint8 codes (4x smaller, exact)")
     p.add_argument("--k_epochs", type=int, default=10)
     p.add_argument("--gae_lambda", type=float, default=0.0)
@@ -74,6 +76,7 @@ def main(argv=None, predictor=False):
     agent.gamma, agent.K_epochs = args.gamma, args.k_epochs
     agent.gae_lambda, agent.use_done_mask, agent.normalize_adv = args.gae_lambda, args.gae_lambda > 0, args.normalize_adv
     agent.sample_seed = (seed or 0) + 7919 * rank
+    agent.amp_dtype = torch.bfloat16 if args.amp == "bf16" else None
     agent.to(device)
     twdist.broadcast_parameters([agent.actor, agent.critic] +
                                 ([agent.encoder, agent.decoder, agent.predictor] if predictor else []))
