@@ -32,6 +32,19 @@ ap.add_argument("--frame_codes", action="store_true")
 ap.add_argument("--her", action="store_true")
 a = ap.parse_args()
 
+
+def _heartbeat():                              # MIOpen's first-call kernel search can take minutes per shape
+    import threading
+    t0 = time.perf_counter()
+
+    def beat():
+        while True:
+            time.sleep(60)
+            print("... %.0f s" % (time.perf_counter() - t0), file=sys.stderr, flush=True)
+    threading.Thread(target=beat, daemon=True).start()
+
+
+_heartbeat()
 torch.manual_seed(9981)
 eng = TwoarmyEngine(a.variant, a.envs, 17, seed=9981)
 agent = PPO()
