@@ -120,16 +120,6 @@ class PPO:
         self.actor.to(device); self.critic.to(device)
         return self
 
-    def set_channels_last(self, enable=True):
-        """NHWC conv activations + weights (same arithmetic, different MIOpen kernels: removes the NCHW<->NHWC
-        transposes that are ~26 % of the fp32 update, profiles/r01_ppo_fp32_kernel_stats_top45.csv)."""
-        for net in (self.actor, self.critic):
-            for m in net.modules():
-                if hasattr(m, "channels_last"):
-                    m.channels_last = bool(enable)
-            net.to(memory_format=torch.channels_last if enable else torch.contiguous_format)
-        return self
-
     def select_action(self, state_matrix, states_stack, goal, device):
         """Reference signature (PPO.py:73-92): 5-deep numpy stacks in, python (action, log-prob) out."""
         sm = torch.as_tensor(np.asarray(state_matrix)[1:5], dtype=torch.float32, device=device).unsqueeze(0)

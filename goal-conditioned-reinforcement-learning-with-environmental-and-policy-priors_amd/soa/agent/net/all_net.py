@@ -59,7 +59,6 @@ class TINet(nn.Module):
         self.fc0 = nn.Linear(2304, 256)
         self.fc1 = nn.Linear(256 + 128, 512)
         self.upsamplingnearest = nn.UpsamplingNearest2d(scale_factor=4)
-        self.channels_last = False            # NHWC activations: MIOpen's igemm kernels without layout transposes
         self.apply(reference_init)
 
     def widen_input(self, in_frames):
@@ -70,10 +69,7 @@ class TINet(nn.Module):
         B, F, _ = state_matrix.shape
         coords = torch.cat([position.contiguous().view(B, -1), goal], dim=1)
         coords = torch.relu(self.positionnet(coords))
-        img = state_matrix.contiguous().view(B, F, GRID, GRID)
-        if self.channels_last:
-            img = img.contiguous(memory_format=torch.channels_last)
-        img = self.upsamplingnearest(img)
+        img = self.upsamplingnearest(state_matrix.contiguous().view(B, F, GRID, GRID))
         feat = torch.relu(self.fc0(self.cnn_base(img)))
         return torch.relu(self.fc1(torch.cat([feat, coords], dim=1)))
 

@@ -41,7 +41,6 @@ def build_parser():
     p.add_argument("--updates", type=int, default=1)
     p.add_argument("--amp", default="fp32", choices=["fp32", "bf16"],
                    help="GEMM dtype of the actor-critic (bf16 = torch.autocast, no parity claim; fp32 = reference)")
-    p.add_argument("--channels_last", action="store_true", help="NHWC conv activations/weights (faster MIOpen path)")
     p.add_argument("--frame_codes", action="store_true", help="store rollout frames as uint8 codes (4x smaller, exact)")
     p.add_argument("--k_epochs", type=int, default=10)
     p.add_argument("--gae_lambda", type=float, default=0.0)
@@ -79,8 +78,6 @@ def main(argv=None, predictor=False):
     agent.sample_seed = (seed or 0) + 7919 * rank
     agent.amp_dtype = torch.bfloat16 if args.amp == "bf16" else None
     agent.to(device)
-    if args.channels_last:
-        agent.set_channels_last(True)
     twdist.broadcast_parameters([agent.actor, agent.critic] +
                                 ([agent.encoder, agent.decoder, agent.predictor] if predictor else []))
     if world > 1:

@@ -30,7 +30,6 @@ ap.add_argument("--variant", type=int, default=6)
 ap.add_argument("--amp", default="fp32", choices=["fp32", "bf16"])
 ap.add_argument("--frame_codes", action="store_true")
 ap.add_argument("--her", action="store_true")
-ap.add_argument("--channels_last", action="store_true")
 a = ap.parse_args()
 
 
@@ -51,9 +50,6 @@ eng = TwoarmyEngine(a.variant, a.envs, 17, seed=9981)
 agent = PPO()
 agent.K_epochs = a.k_epochs
 agent.amp_dtype = torch.bfloat16 if a.amp == "bf16" else None
-if a.channels_last:
-    agent.to(eng.device)
-    agent.set_channels_last(True)
 tr = VecPPOTrainer(agent, eng, rollout_steps=a.T, minibatch=a.minibatch, frame_codes=a.frame_codes)
 roll, upd, recs = [], [], []
 for u in range(a.updates + 1):                 # first pass = warm-up (MIOpen find, allocator)
@@ -82,8 +78,7 @@ flop_roll = S * FWD_FLOP_PER_SAMPLE_PER_NET                                   # 
 flop_upd = samples * FWD_FLOP_PER_SAMPLE_PER_NET * (2 + a.k_epochs * 3 * 2)    # 2 critic fwd (targets) + K x (fwd+bwd) x 2 nets
 print(json.dumps({"workload": "full PPO, twoarmy-v%d, %d envs x %d steps, minibatch %d, K=%d, GEMM dtype %s%s%s"
                               % (a.variant, a.envs, a.T, a.minibatch, a.k_epochs, a.amp,
-                                 ", code frames" if a.frame_codes else "",
-                                 (", HER" if a.her else "") + (", NHWC" if a.channels_last else "")),
+                                 ", code frames" if a.frame_codes else "", ", HER" if a.her else ""),
                   "rollout_s": r, "update_s": w, "env_steps_per_s_rollout": S / r, "env_steps_per_s_loop": S / (r + w),
                   "rollout_TFLOPs": flop_roll / r / 1e12, "update_TFLOPs": flop_upd / w / 1e12,
                   "her_records": sum(recs) / len(recs), "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}))
