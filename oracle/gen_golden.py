@@ -5,7 +5,7 @@ TEST INFRASTRUCTURE ONLY.  Imports /root/reference through oracle/ref_harness.py
 classes with scripted / seeded inputs and writes small .npz fixtures into tests/golden/.
 Only data (inputs + the reference's outputs) is written; no reference source text is stored.
 
-  python oracle/gen_golden.py [traces] [views] [her] [ppo] [predictor]     (default: all)
+  python oracle/gen_golden.py [traces] [views] [her] [ppo] [predictor] [occlusion]     (default: all)
 
 The random draws of Twoarmy (np.random.choice calls in twoarmy_v{4,6}.py) are replaced by the
 engine's counter-based Philox words (oracle/philox.py) through ref_harness.patched_choice, so
@@ -506,7 +506,76 @@ def gen_predictor():
                                                                          os.path.getsize(path_out) / 1024))
 
 
-STAGES = {"traces": gen_traces, "views": gen_views, "ppo": gen_ppo, "her": gen_her, "predictor": gen_predictor}
+
+# ----------------------------------------------------------------------------- general MiniGrid views
+def gen_occlusion():
+    """MiniGridEnv.gen_obs / gen_obs_grid with see_through_walls False and True on random W x H grids holding
+    every object class of the reference (walls, doors in all three states, keys, balls, boxes, goal, lava,
+    floor), all four agent directions, odd view sizes 3..11, with and without a carried object
+    (minigrid.py:1443-1496, process_vis :795-832, slice/rotate_left :627-660, encode :749-772)."""
+    rh.setup()
+    import gym_minigrid.minigrid as mg
+    rs = np.random.RandomState(4242)
+    env = rh.make_env("v6").unwrapped
+    colors = list(mg.COLOR_TO_IDX.keys())
+
+    def rand_obj():
+        k = rs.randint(0, 100)
+        c = colors[rs.randint(len(colors))]
+        if k < 40:
+            return None
+        if k < 58:
+            return mg.Wall()
+        if k < 70:
+            st = rs.randint(3)
+            return mg.Door(c, is_open=(st == 0), is_locked=(st == 2))
+        if k < 76:
+            return mg.Key(c)
+        if k < 82:
+            return mg.Ball(c)
+        if k < 88:
+            return mg.Box(c)
+        if k < 92:
+            return mg.Goal()
+        if k < 96:
+            return mg.Lava()
+        return mg.Floor(c)
+
+    out = {}
+    ncase = 0
+    for (W, H) in [(17, 17), (9, 13), (25, 6), (5, 5), (12, 20)]:
+        for rep in range(6):
+            grid = mg.Grid(W, H)
+            for j in range(H):
+                for i in range(W):
+                    grid.set(i, j, rand_obj())
+            env.grid = grid
+            env.width, env.height = W, H
+            ax, ay = int(rs.randint(W)), int(rs.randint(H))
+            env.agent_pos = (ax, ay)
+            env.agent_dir = int(rs.randint(4))
+            env.carrying = [None, mg.Key("blue"), mg.Ball("red"), mg.Box("yellow")][rs.randint(4)] if rep % 2 else None
+            V = int([3, 5, 7, 9, 11, 7][rep])
+            env.agent_view_size = V
+            enc = grid.encode().astype(np.uint8)                      # [W][H][3] world planes
+            for st in (0, 1):
+                env.see_through_walls = bool(st)
+                obs = env.gen_obs()
+                _, vis = env.gen_obs_grid()
+                out["c%03d_img%d" % (ncase, st)] = obs["image"].astype(np.uint8)
+                out["c%03d_vis%d" % (ncase, st)] = vis.astype(np.uint8)
+            out["c%03d_grid" % ncase] = enc
+            carry = env.carrying.encode() if env.carrying is not None else (0, 0, 0)
+            out["c%03d_meta" % ncase] = np.array([W, H, ax, ay, env.agent_dir, V, int(env.carrying is not None)]
+                                                 + list(carry), np.int32)
+            ncase += 1
+    out["n_cases"] = np.int32(ncase)
+    path_out = os.path.join(GOLD, "occlusion.npz")
+    np.savez_compressed(path_out, **out)
+    print("occlusion: %d cases -> %s (%.1f KB)" % (ncase, path_out, os.path.getsize(path_out) / 1024))
+
+
+STAGES = {"traces": gen_traces, "views": gen_views, "ppo": gen_ppo, "her": gen_her, "predictor": gen_predictor, "occlusion": gen_occlusion}
 
 
 def main(argv):

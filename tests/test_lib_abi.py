@@ -12,7 +12,7 @@ def _declared():
     for fn in os.listdir(os.path.join(ROOT, "include")):
         txt = open(os.path.join(ROOT, "include", fn)).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-        syms |= set(re.findall(r"\b((?:tw|ppo)_[a-z0-9_]+)\s*\(", txt))
+        syms |= set(re.findall(r"\b((?:tw|ppo|mg)_[a-z0-9_]+)\s*\(", txt))
     return syms
 
 
