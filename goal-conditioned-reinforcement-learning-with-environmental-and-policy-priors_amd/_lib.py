@@ -71,6 +71,7 @@ _SIGS.update({
     "ppo_loss_fwd_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "ppo_gather_stack": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "mg_gen_obs": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp]),
+    "mg_step": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "ppo_her_relabel": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u64, C.c_uint32, C.c_uint32, _i, _i, _i, _vp, _vp, _vp,
                                   _vp, _vp, _vp, _vp, _vp]),
     "ppo_gather_stack_u8": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),

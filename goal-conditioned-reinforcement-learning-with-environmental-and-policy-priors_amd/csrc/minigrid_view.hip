@@ -140,6 +140,46 @@ __global__ __launch_bounds__(64) void mg_gen_obs_kernel(const uint8_t *__restric
     if (lane < tail) dst[first + nmid * 4 + lane] = stage[phase + first + nmid * 4 + lane];
 }
 
+// ---------------------------------------------------------------- MiniGridEnv.step (base class, minigrid.py:1333-1441)
+// One thread per env; the world planes are read-only (the reference's reachable actions never edit the grid).
+__global__ void mg_step_kernel(const uint8_t *__restrict__ type, const uint8_t *__restrict__ state, int N, int W, int H,
+                               const int32_t *__restrict__ action, int32_t *__restrict__ agent_x,
+                               int32_t *__restrict__ agent_y, const int32_t *__restrict__ agent_dir,
+                               int32_t *__restrict__ step_count, int max_steps, double *__restrict__ reward,
+                               uint8_t *__restrict__ terminated, uint8_t *__restrict__ truncated,
+                               int32_t *__restrict__ error) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int sc = step_count[n] + 1;                                       // self.step_count += 1 comes first
+    step_count[n] = sc;
+    const int ax = agent_x[n], ay = agent_y[n], dir = agent_dir[n] & 3, a = action[n];
+    const int fx = ax + (dir == 0) - (dir == 2), fy = ay + (dir == 1) - (dir == 3);
+    int err = 0, te = 0, tr = 0;
+    double r = 0.0;
+    if (fx < 0 || fx >= W || fy < 0 || fy >= H) err = 2;                    // fwd_cell = self.grid.get(*fwd_pos): assert
+    else if (!(a == 0 || a == 1 || a == 2 || a == 3 || a == 6)) err = 1;   // falls through to `self.actions.forward`
+    else {
+        const int px = ax - (a == 0) + (a == 1), py = ay - (a == 2) + (a == 3);
+        if (px < 0 || px >= W || py < 0 || py >= H) err = 2;
+        else {
+            const size_t o = (size_t)n * W * H + (size_t)py * W + px;
+            const uint32_t t = type[o];
+            const bool overlap = t <= T_EMPTY || t == 8u || t == 11u || t == 3u || t == 9u ||
+                                 (t == T_DOOR && (state ? state[o] : 0) == 0);
+            if (overlap) { agent_x[n] = px; agent_y[n] = py; }
+            if (t == 8u) {                                             // _reward(), :1061 -- no FMA contraction: Python rounds each op
+                te = 1;
+                r = __dsub_rn(1.0, __dmul_rn(0.9, __ddiv_rn((double)sc, (double)max_steps)));
+            }
+            tr = sc >= max_steps;
+        }
+    }
+    reward[n] = r;
+    terminated[n] = (uint8_t)te;
+    truncated[n] = (uint8_t)tr;
+    if (error) error[n] = err;
+}
+
 size_t view_lds_bytes(int V) {
     const int VV = V * V;
     return (size_t)((VV + 1) & ~1) * 4 + (size_t)V * 8 + (size_t)((VV * 3 + 8 + 3) & ~3);
@@ -157,5 +197,18 @@ extern "C" int mg_gen_obs(const uint8_t *type, const uint8_t *colour, const uint
     hipLaunchKernelGGL(mg_gen_obs_kernel, dim3(n_envs), dim3(64), view_lds_bytes(view_size), (hipStream_t)stream, type,
                        colour, state, n_envs, width, height, agent_x, agent_y, agent_dir, carrying, view_size,
                        see_through_walls ? 1 : 0, image, image_pitch, vis_mask);
+    return hipGetLastError() == hipSuccess ? TW_OK : TW_E_HIP;
+}
+
+extern "C" int mg_step(const uint8_t *type, const uint8_t *state, int n_envs, int width, int height,
+                       const int32_t *action, int32_t *agent_x, int32_t *agent_y, const int32_t *agent_dir,
+                       int32_t *step_count, int max_steps, double *reward, uint8_t *terminated, uint8_t *truncated,
+                       int32_t *error, void *stream) {
+    if (!type || !action || !agent_x || !agent_y || !agent_dir || !step_count || !reward || !terminated || !truncated)
+        return TW_E_ARG;
+    if (n_envs <= 0 || width <= 0 || height <= 0 || max_steps <= 0) return TW_E_ARG;
+    hipLaunchKernelGGL(mg_step_kernel, dim3((n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, type, state, n_envs,
+                       width, height, action, agent_x, agent_y, agent_dir, step_count, max_steps, reward, terminated,
+                       truncated, error);
     return hipGetLastError() == hipSuccess ? TW_OK : TW_E_HIP;
 }

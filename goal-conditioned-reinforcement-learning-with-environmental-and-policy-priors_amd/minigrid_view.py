@@ -46,3 +46,20 @@ def gen_obs(type_plane, colour_plane, state_plane, width, height, agent_x, agent
         _p(carrying, torch.uint8), V, int(bool(see_through_walls)), _p(image, torch.uint8), 0, _p(mask, torch.uint8),
         C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "mg_gen_obs")
     return image, mask
+
+
+def step(type_plane, state_plane, width, height, action, agent_x, agent_y, agent_dir, step_count, max_steps):
+    """MiniGridEnv.step of the base class for N envs (mg_step): agent_x / agent_y / step_count (int32[N]) are
+    updated in place; -> (reward float64[N], terminated uint8[N], truncated uint8[N], error int32[N])."""
+    N = type_plane.shape[0]
+    dev = type_plane.device
+    reward = torch.empty(N, dtype=torch.float64, device=dev)
+    term = torch.empty(N, dtype=torch.uint8, device=dev)
+    trunc = torch.empty(N, dtype=torch.uint8, device=dev)
+    err = torch.empty(N, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().mg_step(
+        _p(type_plane, torch.uint8), _p(state_plane, torch.uint8), N, int(width), int(height), _p(action, torch.int32),
+        _p(agent_x, torch.int32), _p(agent_y, torch.int32), _p(agent_dir, torch.int32), _p(step_count, torch.int32),
+        int(max_steps), _p(reward, torch.float64), _p(term, torch.uint8), _p(trunc, torch.uint8), _p(err, torch.int32),
+        C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "mg_step")
+    return reward, term, trunc, err

@@ -36,6 +36,21 @@ int mg_gen_obs(const uint8_t *type, const uint8_t *colour, const uint8_t *state,
                const int32_t *agent_x, const int32_t *agent_y, const int32_t *agent_dir, const uint8_t *carrying,
                int view_size, int see_through_walls, uint8_t *image, int image_pitch, uint8_t *vis_mask, void *stream);
 
+/* MiniGridEnv.step of the base class (minigrid.py:1333-1441) without the observation (call mg_gen_obs next):
+ * step_count += 1; the cell in front of the agent is fetched first (an out-of-range front cell is the reference's
+ * AssertionError even for sideways moves); actions 0 left, 1 right, 2 up, 3 down, 6 done(stay) are absolute moves
+ * onto empty cells or objects with can_overlap() (goal, subgoal, floor, lava, open door); reaching a goal ->
+ * terminated and reward = 1 - 0.9 * step_count / max_steps (_reward, :1061, in double like the Python float);
+ * truncated = step_count >= max_steps.  Any other action value reaches `self.actions.forward`, which the
+ * reference's Actions enum does not define (:1397).  The world planes are never modified (drop / toggle are
+ * unreachable in the reference).
+ *   error int32[N] (nullable): 0 ok, 1 AttributeError (action outside {0,1,2,3,6}), 2 AssertionError (Grid.get out
+ *   of range); on an error the env keeps the mutation the reference had made (step_count) and reports reward 0,
+ *   terminated = truncated = 0.  agent_x / agent_y / step_count are updated in place. */
+int mg_step(const uint8_t *type, const uint8_t *state, int n_envs, int width, int height, const int32_t *action,
+            int32_t *agent_x, int32_t *agent_y, const int32_t *agent_dir, int32_t *step_count, int max_steps,
+            double *reward, uint8_t *terminated, uint8_t *truncated, int32_t *error, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,7 +5,7 @@ TEST INFRASTRUCTURE ONLY.  Imports /root/reference through oracle/ref_harness.py
 classes with scripted / seeded inputs and writes small .npz fixtures into tests/golden/.
 Only data (inputs + the reference's outputs) is written; no reference source text is stored.
 
-  python oracle/gen_golden.py [traces] [views] [her] [ppo] [predictor] [occlusion]     (default: all)
+  python oracle/gen_golden.py [traces] [views] [her] [ppo] [predictor] [occlusion] [mgstep]     (default: all)
 
 The random draws of Twoarmy (np.random.choice calls in twoarmy_v{4,6}.py) are replaced by the
 engine's counter-based Philox words (oracle/philox.py) through ref_harness.patched_choice, so
@@ -575,7 +575,63 @@ def gen_occlusion():
     print("occlusion: %d cases -> %s (%.1f KB)" % (ncase, path_out, os.path.getsize(path_out) / 1024))
 
 
-STAGES = {"traces": gen_traces, "views": gen_views, "ppo": gen_ppo, "her": gen_her, "predictor": gen_predictor, "occlusion": gen_occlusion}
+def gen_mgstep():
+    """MiniGridEnv.step (the base-class transition, minigrid.py:1333-1441) on random worlds: absolute moves with the
+    can_overlap rules of every object class, goal termination with _reward() (:1061), truncation, and the
+    exceptions of out-of-range cells / actions outside {left,right,up,down,done}."""
+    rh.setup()
+    import gym_minigrid.minigrid as mg
+    rs = np.random.RandomState(777)
+    env = rh.make_env("v6").unwrapped
+    colors = list(mg.COLOR_TO_IDX.keys())
+    makers = [lambda c: None, lambda c: None, lambda c: mg.Wall(), lambda c: mg.Door(c, is_open=True),
+              lambda c: mg.Door(c), lambda c: mg.Door(c, is_locked=True), lambda c: mg.Key(c), lambda c: mg.Ball(c),
+              lambda c: mg.Box(c), lambda c: mg.Goal(), lambda c: mg.Lava(), lambda c: mg.Floor(c), lambda c: mg.SubGoal()]
+    out = {}
+    ncase = 0
+    for (W, H) in [(7, 7), (5, 9), (12, 4)]:
+        for rep in range(4):
+            grid = mg.Grid(W, H)
+            for j in range(H):
+                for i in range(W):
+                    grid.set(i, j, makers[rs.randint(len(makers))](colors[rs.randint(len(colors))]))
+            env.grid, env.width, env.height = grid, W, H
+            env.max_steps = int([50, 20, 9, 33][rep])
+            env.see_through_walls = True
+            env.agent_view_size = 3
+            env.carrying = None
+            rows = []
+            env.agent_pos = (int(rs.randint(W)), int(rs.randint(H)))
+            env.agent_dir = int(rs.randint(4))
+            env.step_count = 0
+            for t in range(60):
+                if rs.rand() < 0.15:                       # teleport: visit borders and every object class
+                    env.agent_pos = (int(rs.randint(W)), int(rs.randint(H)))
+                    env.agent_dir = int(rs.randint(4))
+                a = int(rs.choice([0, 1, 2, 3, 6, 0, 1, 2, 3, 6, 4, 5, 7, -1]))
+                before = (int(env.agent_pos[0]), int(env.agent_pos[1]), int(env.agent_dir), int(env.step_count))
+                err, r, te, tr = 0, 0.0, False, False
+                try:
+                    _, r, te, tr, _ = mg.MiniGridEnv.step(env, a)
+                except AttributeError:
+                    err = 1
+                except AssertionError:
+                    err = 2
+                except ValueError:
+                    err = 4
+                rows.append(before + (a, int(env.agent_pos[0]), int(env.agent_pos[1]), int(env.step_count), err,
+                                      int(te), int(tr)) + (float(r),))
+            out["c%02d_grid" % ncase] = grid.encode().astype(np.uint8)
+            out["c%02d_rows" % ncase] = np.array(rows, np.float64)
+            out["c%02d_meta" % ncase] = np.array([W, H, env.max_steps], np.int32)
+            ncase += 1
+    out["n_cases"] = np.int32(ncase)
+    path_out = os.path.join(GOLD, "mgstep.npz")
+    np.savez_compressed(path_out, **out)
+    print("mgstep: %d cases -> %s (%.1f KB)" % (ncase, path_out, os.path.getsize(path_out) / 1024))
+
+
+STAGES = {"traces": gen_traces, "views": gen_views, "ppo": gen_ppo, "her": gen_her, "predictor": gen_predictor, "occlusion": gen_occlusion, "mgstep": gen_mgstep}
 
 
 def main(argv):

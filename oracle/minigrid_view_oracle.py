@@ -143,3 +143,57 @@ def gen_obs_batch(enc, ax, ay, agent_dir, V, see_through_walls, carrying=None):
         img[n], m = gen_obs(enc[n], int(ax[n]), int(ay[n]), int(agent_dir[n]), V, see_through_walls, c)
         vis[n] = m
     return img, vis
+
+
+# ----------------------------------------------------------------------------- MiniGridEnv.step (base class)
+DIR_TO_VEC = ((1, 0), (0, 1), (-1, 0), (0, -1))                 # minigrid.py:70-79
+A_LEFT, A_RIGHT, A_UP, A_DOWN, A_DROP, A_TOGGLE, A_DONE = 0, 1, 2, 3, 4, 5, 6   # Actions, minigrid.py:849-864
+E_ATTRIBUTE, E_ASSERTION = 1, 2
+
+
+def can_overlap(cell):
+    """WorldObj :291-293 (False); Goal :361, SubGoal :371, Floor :386, Lava :399 (True); Door :435-437 (is_open)."""
+    if cell is None:
+        return True
+    t = cell[0]
+    if t in (8, 11, 3, 9):
+        return True
+    if t == DOOR:
+        return cell[2] == 0
+    return False
+
+
+def step(world, ax, ay, agent_dir, step_count, max_steps, action):
+    """MiniGridEnv.step :1333-1441 without the final gen_obs.  `world` = Grid of encoded cells.
+    -> (ax, ay, step_count, error, terminated, truncated, reward); on an exception the state is returned as far as
+    the reference had mutated it (step_count already incremented) with error 1 = AttributeError (the action falls
+    through to `self.actions.forward`, which the Actions enum lacks, :1397) or 2 = AssertionError (Grid.get out of
+    range, :604-606)."""
+    step_count += 1
+    reward, terminated, truncated = 0.0, False, False
+
+    def get(i, j):
+        if not (0 <= i < world.width and 0 <= j < world.height):
+            raise AssertionError
+        return world.get(i, j)
+
+    try:
+        get(ax + DIR_TO_VEC[agent_dir][0], ay + DIR_TO_VEC[agent_dir][1])          # fwd_cell, :1341-1344
+        moves = {A_LEFT: (-1, 0), A_RIGHT: (1, 0), A_UP: (0, -1), A_DOWN: (0, 1), A_DONE: (0, 0)}
+        if action in moves:
+            px, py = ax + moves[action][0], ay + moves[action][1]
+            cell = get(px, py)
+            if cell is None or can_overlap(cell):
+                ax, ay = px, py
+            if cell is not None and cell[0] == 8:
+                terminated = True
+                reward = 1 - 0.9 * (step_count / max_steps)                        # _reward(), :1061
+        else:
+            raise AttributeError                                                   # `self.actions.forward`, :1397
+    except AttributeError:
+        return ax, ay, step_count, E_ATTRIBUTE, False, False, 0.0
+    except AssertionError:
+        return ax, ay, step_count, E_ASSERTION, False, False, 0.0
+    if step_count >= max_steps:
+        truncated = True
+    return ax, ay, step_count, 0, terminated, truncated, reward

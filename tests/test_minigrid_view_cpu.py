@@ -25,3 +25,24 @@ def test_view_oracle_matches_reference(golden_dir):
         occluded += int((c["vis"][0] == 0).sum())
         n += 1
     assert n == 30 and occluded > 100          # the occlusion path is really exercised
+
+
+def load_step_cases(golden_dir):
+    z = np.load(golden_dir + "/mgstep.npz")
+    for ci in range(int(z["n_cases"])):
+        W, H, max_steps = (int(v) for v in z["c%02d_meta" % ci])
+        yield dict(ci=ci, W=W, H=H, max_steps=max_steps, grid=z["c%02d_grid" % ci], rows=z["c%02d_rows" % ci])
+
+
+def test_step_oracle_matches_reference(golden_dir):
+    """rows: ax, ay, dir, step_count before | action | ax, ay, step_count after, error, terminated, truncated, reward."""
+    n = 0
+    for c in load_step_cases(golden_dir):
+        world = mvo.Grid.from_encoded(c["grid"])
+        for row in c["rows"]:
+            ax, ay, d, sc, a = (int(v) for v in row[:5])
+            got = mvo.step(world, ax, ay, d, sc, c["max_steps"], a)
+            want = tuple(int(v) for v in row[5:11]) + (float(row[11]),)
+            assert got[:4] == want[:4] and (int(got[4]), int(got[5])) == want[4:6] and got[6] == want[6], (c["ci"], row)
+            n += 1
+    assert n == 720

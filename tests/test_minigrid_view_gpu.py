@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import minigrid_view_oracle as mvo
-from test_minigrid_view_cpu import load_cases
+from test_minigrid_view_cpu import load_cases, load_step_cases
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -73,3 +73,41 @@ def test_twoarmy_engine_view_agrees_with_general_kernel():
                             f("AY"), torch.full((N,), 3, dtype=torch.int32, device=DEV), V, True)
         assert np.array_equal(img.cpu().numpy(), want), V
     eng.close()
+
+
+def test_step_kernel_matches_reference_goldens(golden_dir):
+    """mg_step on the 720 transitions recorded from the reference's MiniGridEnv.step (moves, overlap rules of every
+    object class, goal reward, truncation, both exception kinds)."""
+    from twoarmy_amd import minigrid_view as mv
+    total = 0
+    for c in load_step_cases(golden_dir):
+        rows = c["rows"]
+        B = len(rows)
+        ty, _, st = (p.to(DEV) for p in mv.planes_from_encoded(np.repeat(c["grid"][None], B, 0)))
+        col = lambda k: torch.tensor(rows[:, k].astype(np.int32), device=DEV)                 # noqa: E731
+        ax, ay, d, sc, a = col(0), col(1), col(2), col(3), col(4)
+        r, te, tr, err = mv.step(ty, st, c["W"], c["H"], a, ax, ay, d, sc, c["max_steps"])
+        got = np.stack([v.cpu().numpy().astype(np.float64) for v in (ax, ay, sc, err, te, tr, r)], 1)
+        assert np.array_equal(got, rows[:, 5:12]), c["ci"]
+        total += B
+    assert total == 720
+
+
+def test_step_kernel_matches_oracle_random():
+    from twoarmy_amd import minigrid_view as mv
+    rs = np.random.RandomState(5)
+    N, W, H, max_steps = 3000, 9, 6, 17
+    ty = rs.choice([1, 1, 1, 2, 3, 4, 4, 5, 6, 7, 8, 9, 11], size=(N, W, H)).astype(np.uint8)
+    st = np.where(ty == 4, rs.randint(0, 3, size=(N, W, H)), 0).astype(np.uint8)
+    enc = np.stack([ty, np.zeros_like(ty), st], -1)
+    ax, ay, d = rs.randint(0, W, N), rs.randint(0, H, N), rs.randint(0, 4, N)
+    sc, a = rs.randint(0, 20, N), rs.choice([0, 1, 2, 3, 6, 4, 5, 9, -3], N)
+    want = np.array([mvo.step(mvo.Grid.from_encoded(enc[n]), int(ax[n]), int(ay[n]), int(d[n]), int(sc[n]), max_steps,
+                              int(a[n])) for n in range(N)], np.float64)
+    t = lambda v: torch.tensor(v.astype(np.int32), device=DEV)                               # noqa: E731
+    tp, _, sp = (p.to(DEV) for p in mv.planes_from_encoded(enc))
+    gx, gy, gs = t(ax), t(ay), t(sc)
+    r, te, tr, err = mv.step(tp, sp, W, H, t(a), gx, gy, t(d), gs, max_steps)
+    got = np.stack([v.cpu().numpy().astype(np.float64) for v in (gx, gy, gs, err, te, tr, r)], 1)
+    assert np.array_equal(got, want)
+    assert want[:, 4].sum() > 0 and (want[:, 3] == 1).sum() > 0 and (want[:, 3] == 2).sum() > 0
