@@ -140,6 +140,15 @@ __global__ __launch_bounds__(64) void mg_gen_obs_kernel(const uint8_t *__restric
     if (lane < tail) dst[first + nmid * 4 + lane] = stage[phase + first + nmid * 4 + lane];
 }
 
+// _reward() = 1 - 0.9 * (step_count / max_steps) as Python evaluates it: three separately rounded double operations.
+// (__dmul_rn / __dsub_rn are plain operators in HIP and would still be contracted into one fma.)
+__device__ __forceinline__ double reference_reward(int step_count, int max_steps) {
+#pragma clang fp contract(off)
+    const double q = (double)step_count / (double)max_steps;
+    const double m = 0.9 * q;
+    return 1.0 - m;
+}
+
 // ---------------------------------------------------------------- MiniGridEnv.step (base class, minigrid.py:1333-1441)
 // One thread per env; the world planes are read-only (the reference's reachable actions never edit the grid).
 __global__ void mg_step_kernel(const uint8_t *__restrict__ type, const uint8_t *__restrict__ state, int N, int W, int H,
@@ -167,10 +176,7 @@ __global__ void mg_step_kernel(const uint8_t *__restrict__ type, const uint8_t *
             const bool overlap = t <= T_EMPTY || t == 8u || t == 11u || t == 3u || t == 9u ||
                                  (t == T_DOOR && (state ? state[o] : 0) == 0);
             if (overlap) { agent_x[n] = px; agent_y[n] = py; }
-            if (t == 8u) {                                             // _reward(), :1061 -- no FMA contraction: Python rounds each op
-                te = 1;
-                r = __dsub_rn(1.0, __dmul_rn(0.9, __ddiv_rn((double)sc, (double)max_steps)));
-            }
+            if (t == 8u) { te = 1; r = reference_reward(sc, max_steps); }                  // _reward(), :1061
             tr = sc >= max_steps;
         }
     }

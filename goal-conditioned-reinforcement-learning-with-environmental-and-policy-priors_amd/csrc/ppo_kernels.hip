@@ -90,10 +90,11 @@ __global__ __launch_bounds__(256) void ppo_gae_kernel(const float *__restrict__ 
             if (t < T && n < N) {
                 const size_t i = (size_t)t * N + n;
                 const float cut = (use_done_mask && done[i]) ? 0.f : 1.f;
-                // same rounding sequence as torch: g*V, * cut, + r, - V   (no fma contraction)
-                const float tv = __fadd_rn(reward[i], __fmul_rn(__fmul_rn(gamma, next_value[i]), cut));
+                // same rounding sequence as torch: g*V, * cut, + r, - V.  cut is 0 or 1, so a contracted
+                // fma(cut, g*V, r) rounds exactly like the separate multiply and add.
+                const float tv = reward[i] + (gamma * next_value[i]) * cut;
                 if (target) target[i] = tv;
-                d = __fsub_rn(tv, value[i]);
+                d = tv - value[i];
                 c = gamma * lambda * cut;
             }
             sd[r][tx] = d; sc[r][tx] = c;
