@@ -52,18 +52,20 @@ __device__ __forceinline__ uint64_t flood_left(uint64_t m, uint64_t q) {
 
 // One wavefront serves E = 64 / V envs: a view row of all of them sits in one 64-bit mask (env e owns bits
 // e*V .. e*V+V-1), so one ballot + one pair of floods resolves that row of process_vis for E envs at once.
+template <int VT>                                                          // VT > 0: view size known at compile time
 __global__ __launch_bounds__(64) void mg_gen_obs_kernel(const uint8_t *__restrict__ type, const uint8_t *__restrict__ colour,
                                                         const uint8_t *__restrict__ state, int N, int W, int H,
                                                         const int32_t *__restrict__ agent_x,
                                                         const int32_t *__restrict__ agent_y,
                                                         const int32_t *__restrict__ agent_dir,
-                                                        const uint8_t *__restrict__ carrying, int V, int E, int see_through,
+                                                        const uint8_t *__restrict__ carrying, int v_rt, int see_through,
                                                         uint8_t *__restrict__ image, int image_pitch,
                                                         uint8_t *__restrict__ vis_mask) {
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x;
+    const int V = VT ? VT : v_rt, E = 64 / V;
     const int n0 = blockIdx.x * E;
-    const int VV = V * V, EV = E * V, nb = VV * 3;
+    const int VV = V * V, EV = E * V, nb = VV * 3, nbp = (nb + 6) & ~3;     // nbp: staged bytes per env incl. alignment phase
     const int ne = N - n0 < E ? N - n0 : E;                                 // envs of this wavefront
     uint32_t *cells = lds;                                                  // [e][j][i]: type | colour << 8 | state << 16
     uint64_t *rowmask = reinterpret_cast<uint64_t *>(lds + ((E * VV + 1) & ~1));   // [j]: bit e*V+i = cell (i, j) of env e visible
@@ -71,7 +73,10 @@ __global__ __launch_bounds__(64) void mg_gen_obs_kernel(const uint8_t *__restric
     int32_t *topy = topx + E;
     int32_t *rot = topy + E;
     uint32_t *carried = reinterpret_cast<uint32_t *>(rot + E);
-    uint8_t *stage = reinterpret_cast<uint8_t *>(carried + E);              // [e][i][j][3]: image bytes in output order
+    int32_t *phase = reinterpret_cast<int32_t *>(carried + E);              // [e] (address of the env's image) & 3
+    uint8_t *stage = reinterpret_cast<uint8_t *>(phase + E);                // [e][phase + (i*V + j)*3 + ch]: output order, and
+                                                                            // 4-byte aligned exactly where the destination is
+    const size_t pitch = image_pitch ? (size_t)image_pitch : (size_t)nb;
 
     const int half = V / 2;
     if (lane < ne) {
@@ -86,6 +91,7 @@ __global__ __launch_bounds__(64) void mg_gen_obs_kernel(const uint8_t *__restric
             c = carrying[(size_t)n * 3] | ((uint32_t)carrying[(size_t)n * 3 + 1] << 8) |
                 ((uint32_t)carrying[(size_t)n * 3 + 2] << 16);
         carried[lane] = c;
+        phase[lane] = (int)((uintptr_t)(image + (size_t)n * pitch) & 3u);
     }
     wsync();
     for (int c = lane; c < ne * VV; c += 64) {
@@ -137,22 +143,20 @@ __global__ __launch_bounds__(64) void mg_gen_obs_kernel(const uint8_t *__restric
         uint32_t cell = cells[c];
         if (i == half && j == V - 1) cell = carried[e];                     // grid.set(*agent_pos, carrying or None)
         if (!vis) cell = 0u;
-        uint8_t *s = stage + (size_t)e * nb + (size_t)(i * V + j) * 3;
+        uint8_t *s = stage + e * nbp + phase[e] + (i * V + j) * 3;
         s[0] = (uint8_t)cell; s[1] = (uint8_t)(cell >> 8); s[2] = (uint8_t)(cell >> 16);
         if (vis_mask) vis_mask[(size_t)(n0 + e) * VV + i * V + j] = vis ? 1 : 0;
     }
     wsync();
     // ---- copy out: per env, the 4-byte aligned slots that overlap its image; whole slots leave as dwords
-    const size_t pitch = image_pitch ? (size_t)image_pitch : (size_t)nb;
     const int slots = (nb + 3) / 4 + 1;
     for (int idx = lane; idx < ne * slots; idx += 64) {
         const int e = idx / slots, d = idx - e * slots;
         uint8_t *dst = image + (size_t)(n0 + e) * pitch;
-        const int b0 = 4 * d - (int)((uintptr_t)dst & 3u);                  // first image byte of this slot (may be < 0)
-        const uint8_t *s = stage + (size_t)e * nb;
+        const int b0 = 4 * d - phase[e];                                    // first image byte of this slot (may be < 0)
+        const uint8_t *s = stage + e * nbp + phase[e];
         if (b0 >= 0 && b0 + 3 < nb) {
-            *reinterpret_cast<uint32_t *>(dst + b0) =
-                (uint32_t)s[b0] | ((uint32_t)s[b0 + 1] << 8) | ((uint32_t)s[b0 + 2] << 16) | ((uint32_t)s[b0 + 3] << 24);
+            *reinterpret_cast<uint32_t *>(dst + b0) = *reinterpret_cast<const uint32_t *>(s + b0);
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -209,7 +213,7 @@ __global__ void mg_step_kernel(const uint8_t *__restrict__ type, const uint8_t *
 
 size_t view_lds_bytes(int V, int E) {
     const int VV = V * V;
-    return (size_t)((E * VV + 1) & ~1) * 4 + (size_t)V * 8 + (size_t)E * 16 + (size_t)((E * VV * 3 + 3) & ~3);
+    return (size_t)((E * VV + 1) & ~1) * 4 + (size_t)V * 8 + (size_t)E * 20 + (size_t)E * ((VV * 3 + 6) & ~3);
 }
 
 }  // namespace
@@ -222,9 +226,24 @@ extern "C" int mg_gen_obs(const uint8_t *type, const uint8_t *colour, const uint
     if (n_envs <= 0 || width <= 0 || height <= 0 || view_size < 1 || view_size > MG_MAX_VIEW) return TW_E_ARG;
     if (image_pitch != 0 && image_pitch < view_size * view_size * 3) return TW_E_ARG;
     const int E = 64 / view_size;                                          // envs per wavefront (2 for V = 31 ... 64 for V = 1)
-    hipLaunchKernelGGL(mg_gen_obs_kernel, dim3((n_envs + E - 1) / E), dim3(64), view_lds_bytes(view_size, E),
-                       (hipStream_t)stream, type, colour, state, n_envs, width, height, agent_x, agent_y, agent_dir,
-                       carrying, view_size, E, see_through_walls ? 1 : 0, image, image_pitch, vis_mask);
+    const dim3 grid((n_envs + E - 1) / E), block(64);
+    const size_t lds = view_lds_bytes(view_size, E);
+#define MG_LAUNCH(VT)                                                                                                  \
+    hipLaunchKernelGGL(mg_gen_obs_kernel<VT>, grid, block, lds, (hipStream_t)stream, type, colour, state, n_envs, width, \
+                       height, agent_x, agent_y, agent_dir, carrying, view_size, see_through_walls ? 1 : 0, image,      \
+                       image_pitch, vis_mask)
+    switch (view_size) {                    // the usual odd sizes get compile-time index arithmetic
+    case 3: MG_LAUNCH(3); break;
+    case 5: MG_LAUNCH(5); break;
+    case 7: MG_LAUNCH(7); break;
+    case 9: MG_LAUNCH(9); break;
+    case 11: MG_LAUNCH(11); break;
+    case 13: MG_LAUNCH(13); break;
+    case 15: MG_LAUNCH(15); break;
+    case 17: MG_LAUNCH(17); break;
+    default: MG_LAUNCH(0); break;
+    }
+#undef MG_LAUNCH
     return hipGetLastError() == hipSuccess ? TW_OK : TW_E_HIP;
 }
 
