@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""A/B timing of diagnostic library builds in ONE process on ONE box (box-to-box variance is ~25 %):
+python tools/ab_variants.py std xcd nt ...   (suffixes of libtwoarmy_hip_<suffix>.so, "std" = the shipped library).
+Each variant is loaded as its own ctypes handle; rounds are interleaved."""
+import ctypes as C
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa
+import twoarmy_amd  # noqa
+from twoarmy_amd import _lib, engine as eng_mod  # noqa
+
+T, N = 128, 4096
+names = sys.argv[1:] or ["std"]
+engines = {}
+base = _lib.LIB_PATH
+for nm in names:
+    _lib._lib = None
+    _lib.LIB_PATH = base if nm == "std" else os.path.join(os.path.dirname(base), "libtwoarmy_hip_%s.so" % nm)
+    lib = _lib.lib()                                    # binds signatures on this handle
+    e = eng_mod.TwoarmyEngine(6, N, 17, seed=9981)
+    engines[nm] = (lib, e, e.fill_actions(T), e.alloc_outputs(T))
+for rnd in range(4):
+    for nm, (lib, e, acts, out) in engines.items():
+        _lib._lib = lib
+        ms = e.time_rollout(T, out, actions=acts, iters=20)
+        print("round %d %-8s %.3f ms/launch  %.3f us/step" % (rnd, nm, ms, ms * 1e3 / T), flush=True)
