@@ -147,7 +147,10 @@ class PPO:
 
     def minibatch_step(self, s0, p0, g, a, old_logp, adv, target_v):
         """One optimiser step on one minibatch (PPO.py:122-147); returns (action_loss, value_loss) tensors."""
-        x0 = self.policy_input(s0)
+        return self.minibatch_step_x(self.policy_input(s0), p0, g, a, old_logp, adv, target_v)
+
+    def minibatch_step_x(self, x0, p0, g, a, old_logp, adv, target_v):
+        """minibatch_step on already assembled network inputs (frames incl. any predicted ones)."""
         probs = self.actor_probs(x0, p0, g)
         value = self.critic_value(x0, p0, g)
         action_loss, value_loss = ppo_ops.ppo_losses(probs, value, a, old_logp, adv, target_v,

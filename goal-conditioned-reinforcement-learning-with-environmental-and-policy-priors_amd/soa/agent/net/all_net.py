@@ -76,14 +76,18 @@ class TINet(nn.Module):
 
 class _Head(nn.Module):
     bone_name, head_name, head_out, in_frames = "", "", 0, 4
+    coord_in = None                 # set: the coordinate MLP is re-created with this many inputs (SoA nets)
 
     def __init__(self):
         super().__init__()
         bone = TINet()
         if self.in_frames != 4:
             bone.widen_input(self.in_frames)
+        if self.coord_in is not None:           # after the conv, like the reference (all_net.py:312-313): RNG order
+            bone.positionnet = nn.Linear(self.coord_in, 128)
         setattr(self, self.bone_name, bone)
-        setattr(self, self.head_name, nn.Linear(512, self.head_out))
+        for name in ([self.head_name] if isinstance(self.head_name, str) else self.head_name):
+            setattr(self, name, nn.Linear(512, self.head_out))
         self.apply(reference_init)
 
     def features(self, state_matrix, position, goal):
@@ -102,6 +106,26 @@ class Net_PPO_critic(_Head):
 
     def forward(self, state_matrix, position, goal, model="actor"):
         return self.V(self.features(state_matrix, position, goal))
+
+
+# ---------------------------------------------------------------------------------------------
+# Self-orientation agent (reference all_net.py:306-401): 8 input frames; actor / critic take the goal plus the
+# predicted 3-step displacement (4 numbers) next to the 4 (y,x) pairs; the orientation net predicts that displacement
+# as two 7-way distributions (offsets -3..3 in y and x).
+class Net_SoA_actor(Net_PPO_actor):
+    in_frames, coord_in = 8, 12
+
+
+class Net_SoA_critic(Net_PPO_critic):
+    in_frames, coord_in = 8, 12
+
+
+class Net_SoA_orient(_Head):
+    bone_name, head_name, head_out, in_frames, coord_in = "bone3", ("Px", "Py"), 7, 8, 10
+
+    def forward(self, state_matrix, position, goal):
+        x = self.features(state_matrix, position, goal)
+        return torch.softmax(self.Px(x), dim=1), torch.softmax(self.Py(x), dim=1)
 
 
 class Net_PPO_Predictor_actor(Net_PPO_actor):

@@ -5,7 +5,7 @@ TEST INFRASTRUCTURE ONLY.  Imports /root/reference through oracle/ref_harness.py
 classes with scripted / seeded inputs and writes small .npz fixtures into tests/golden/.
 Only data (inputs + the reference's outputs) is written; no reference source text is stored.
 
-  python oracle/gen_golden.py [traces] [views] [her] [ppo] [predictor] [occlusion] [mgstep]     (default: all)
+  python oracle/gen_golden.py [traces] [views] [her] [ppo] [predictor] [occlusion] [mgstep] [soa]     (default: all)
 
 The random draws of Twoarmy (np.random.choice calls in twoarmy_v{4,6}.py) are replaced by the
 engine's counter-based Philox words (oracle/philox.py) through ref_harness.patched_choice, so
@@ -507,6 +507,106 @@ def gen_predictor():
 
 
 
+# ----------------------------------------------------------------------------- self-orientation agent
+def gen_soa():
+    """soa/agent/Self_orientation_agent.py: init statistics of the three trainable nets, forward of the orientation
+    head / actor / critic on 8-frame inputs, and the per-minibatch losses of update_policy (:166-239) and
+    update_orientation (:242-294) on 9-frame window records (train_SoA.py:113-117) with seeded weights."""
+    import torch
+    env_buffer, _ = rh.soa_modules()
+    from agent import Self_orientation_agent as so_mod
+    so_mod.heatmap = lambda *a, **k: None
+    so_mod.savetxt = lambda *a, **k: None                 # update_orientation dumps a csv next to its logs
+    out = {}
+    torch.manual_seed(SEED)
+    agent = so_mod.self_orinetation_agent()
+    nets = (("actor", agent.actor), ("critic", agent.critic), ("orient", agent.agent_position_preditor))
+    for tag, net in nets:
+        st = param_stats(net)
+        out["init_%s_names" % tag] = np.array([x[0] for x in st])
+        out["init_%s_sum" % tag] = np.array([x[2] for x in st])
+        out["init_%s_abs" % tag] = np.array([x[3] for x in st])
+    for i, (tag, net) in enumerate(nets):
+        net.load_state_dict(det_weights(net, 21 + i))
+    for i, net in enumerate((agent.encoder, agent.decoder)):
+        net.load_state_dict(det_weights_v2(net, 13 + i))
+    lstm_sd = {}
+    for k, (name, prm) in enumerate(agent.predictor.state_dict().items()):
+        n = prm.numel()
+        lstm_sd[name] = torch.tensor((0.03 * np.sin(0.37 * np.arange(n, dtype=np.float64) + 1.3 * k)).reshape(tuple(prm.shape)),
+                                     dtype=prm.dtype)
+    agent.predictor.load_state_dict(lstm_sd)
+    dev = torch.device("cpu")
+    agent.encoder.device = agent.predictor.device = dev
+    # a real trajectory: per-step frames / positions of the first long episode of a seeded random policy
+    buf = collect_buffer(env_buffer, "v4", 128, seed=6)
+    b = buf.buffer
+    ends = buf.episode_ends
+    e0 = next(i for i, e in enumerate(ends) if (e - (ends[i - 1] + 1 if i else 0)) >= 44)
+    first = ends[e0 - 1] + 1 if e0 else 0
+    L = 44
+    frames = np.concatenate([b['s'][first][:4], b['s'][first:first + L, 4]])       # 4 reset frames + one frame per step
+    poss = np.concatenate([b['p'][first][:4], b['p'][first:first + L, 4]])
+    B = 32
+    rs = np.random.RandomState(11)
+    pre_t = np.dtype([('s', np.float64, (9, 289)), ('a', np.int64, (5, 1)), ('p', np.float64, (9, 2)), ('g', np.float64, (2,)),
+                      ('r', np.float64, (5, 1)), ('d', np.int64, (5, 1)), ('a_logp', np.float64, (5, 1)), ('f', np.float64, (5, 2))])
+    pb = np.zeros(B, dtype=pre_t)
+    for i in range(B):
+        pb['s'][i] = frames[i:i + 9]
+        pb['p'][i] = poss[i:i + 9]
+        pb['g'][i] = b['g'][first]
+        pb['a'][i] = rs.randint(0, 5, (5, 1))
+        pb['r'][i] = rs.choice([-0.01, -0.1, 0.2, 0.9], (5, 1))
+        pb['a_logp'][i] = np.log(0.2) - 0.05 * rs.rand(5, 1)
+        pb['f'][i] = rs.randint(-3, 4, (5, 2))
+    # (1) forward
+    sel = [0, 7, 19]
+    s4 = torch.tensor(pb['s'][sel][:, :4], dtype=torch.float32)
+    p4 = torch.tensor(pb['p'][sel][:, :4], dtype=torch.float32)
+    g = torch.tensor(pb['g'][sel], dtype=torch.float32)
+    f0 = torch.tensor(pb['f'][sel][:, 0], dtype=torch.float32)
+    for m in (agent.actor, agent.critic, agent.agent_position_preditor):
+        m.eval()
+    with torch.no_grad():
+        heads, _, _ = agent.pred_states(s4)
+        x8 = torch.cat([s4, heads], 1)
+        px, py = agent.agent_position_preditor(x8, p4, g)
+        cg = torch.cat([g, f0], 1)
+        out["fwd_px"], out["fwd_py"] = px.numpy(), py.numpy()
+        out["fwd_probs"] = agent.actor(x8, p4, cg).numpy()
+        out["fwd_value"] = agent.critic(x8, p4, cg).numpy()
+    out["fwd_sel"] = np.array(sel)
+    # (2) update_policy: 32 records, minibatch 16, 2 epochs
+    agent.batch_size, agent.K_epochs = 16, 2
+    agent.heatmapfilename = "x"
+    torch.manual_seed(321)
+    st0 = torch.get_rng_state()
+    agent.update_policy(pb, dev, 0)
+    out["pol_action_loss"] = np.array([v for _, v in agent.writer.scalars["loss/action_loss_update"]])
+    out["pol_value_loss"] = np.array([v for _, v in agent.writer.scalars["loss/value_loss_update"]])
+    torch.set_rng_state(st0)
+    out["pol_perms"] = np.stack([torch.randperm(B).numpy() for _ in range(2)])
+    # (3) update_orientation: same records, minibatch 16, 2 epochs
+    agent.batch_size_pre_agent, agent.K_epochs_pre_agent_position = 16, 2
+    agent.future3positionfilename = "/tmp/soa_golden_"
+    torch.manual_seed(654)
+    st1 = torch.get_rng_state()
+    agent.update_orientation(pb, dev, 0)
+    out["ori_loss"] = np.array([v for _, v in agent.writer.scalars["loss/future_3steps_loss_update"]])
+    torch.set_rng_state(st1)
+    out["ori_perms"] = np.stack([torch.randperm(B).numpy() for _ in range(2)])
+    for tag, net in nets:
+        st = param_stats(net)
+        out["upd_%s_sum" % tag] = np.array([x[2] for x in st])
+    for k in pre_t.names:
+        out["buf_" + k] = pb[k]
+    path_out = os.path.join(GOLD, "soa.npz")
+    np.savez_compressed(path_out, **out)
+    print("soa: policy losses", out["pol_action_loss"][:2], out["pol_value_loss"][:2], "orientation", out["ori_loss"][:2],
+          "-> %s (%.1f KB)" % (path_out, os.path.getsize(path_out) / 1024))
+
+
 # ----------------------------------------------------------------------------- general MiniGrid views (SURVEY 8 f2)
 def gen_occlusion():
     """MiniGridEnv.gen_obs / gen_obs_grid with see_through_walls False and True on random W x H grids holding
@@ -631,7 +731,7 @@ def gen_mgstep():
     print("mgstep: %d cases -> %s (%.1f KB)" % (ncase, path_out, os.path.getsize(path_out) / 1024))
 
 
-STAGES = {"traces": gen_traces, "views": gen_views, "ppo": gen_ppo, "her": gen_her, "predictor": gen_predictor, "occlusion": gen_occlusion, "mgstep": gen_mgstep}
+STAGES = {"traces": gen_traces, "views": gen_views, "ppo": gen_ppo, "her": gen_her, "predictor": gen_predictor, "occlusion": gen_occlusion, "mgstep": gen_mgstep, "soa": gen_soa}
 
 
 def main(argv):
