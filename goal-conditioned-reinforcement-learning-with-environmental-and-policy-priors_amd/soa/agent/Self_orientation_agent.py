@@ -32,6 +32,7 @@ class self_orinetation_agent(ppo_predictor):
         self.K_epochs_pre_agent_position = 50
         self.update_count_fp = 0
         self.future3positionfilename = None
+        self.grad_sync_orient = None               # multi-GPU: all-reduce of the orientation head's gradients (dist.py)
         self.optimizer_actor = torch.optim.Adam(self.actor.parameters(), lr=self.lr, eps=1e-5)
         self.optimizer_critic = torch.optim.Adam(self.critic.parameters(), lr=self.lr, eps=1e-5)
         self.optimizer_agent_position_preditor = torch.optim.Adam(self.agent_position_preditor.parameters(), lr=self.lr,
@@ -57,18 +58,23 @@ class self_orinetation_agent(ppo_predictor):
         return a.float(), b.float()
 
     @torch.no_grad()
-    def act_batch_soa(self, frames4, pos4, goal, uniforms=None):
+    def act_batch_soa(self, frames4, pos4, goal, uniforms=None, future=None, orient_only=False):
         """-> (action int32[B], logp f32[B], future f32[B,2]): orientation sample first, then the policy with the
-        goal extended by it (:122-137).  uniforms f32[B,3] (component 0, component 1, action) or None = Philox."""
+        goal extended by it (:122-137).  uniforms f32[B,3] (component 0, component 1, action) or None = Philox.
+        `future` given: that orientation sample is used instead of drawing one; orient_only: no action is drawn."""
         for m in (self.actor, self.critic, self.agent_position_preditor):
             m.eval()
         B = frames4.shape[0]
         x8 = self.policy_input(frames4)
-        p0, p1 = self.orient_probs(x8, pos4, goal)
         u = (None, None, None) if uniforms is None else tuple(uniforms[:, k].contiguous() for k in range(3))
-        i0, _ = ppo_ops.sample(p0, u[0], seed=self.sample_seed, offset=self.sample_count)
-        i1, _ = ppo_ops.sample(p1, u[1], seed=self.sample_seed, offset=self.sample_count + B)
-        future = torch.stack([i0, i1], dim=1).float() - 3.0
+        if future is None:
+            p0, p1 = self.orient_probs(x8, pos4, goal)
+            i0, _ = ppo_ops.sample(p0, u[0], seed=self.sample_seed, offset=self.sample_count)
+            i1, _ = ppo_ops.sample(p1, u[1], seed=self.sample_seed, offset=self.sample_count + B)
+            future = torch.stack([i0, i1], dim=1).float() - 3.0
+        if orient_only:
+            self.sample_count += 3 * B
+            return None, None, future
         probs = self.actor_probs(x8, pos4, torch.cat([goal, future], dim=1))
         a, logp = ppo_ops.sample(probs, u[2], seed=self.sample_seed, offset=self.sample_count + 2 * B)
         self.sample_count += 3 * B
@@ -140,8 +146,8 @@ class self_orinetation_agent(ppo_predictor):
                 - Categorical(probs=p1).log_prob(cls[:, 1]).view(-1, 1)).mean()
         self.optimizer_agent_position_preditor.zero_grad()
         loss.backward()
-        if self.grad_sync is not None:
-            self.grad_sync(list(self.agent_position_preditor.parameters()))
+        if self.grad_sync_orient is not None:
+            self.grad_sync_orient(list(self.agent_position_preditor.parameters()))
         if self.use_grad_clip:
             torch.nn.utils.clip_grad_norm_(self.agent_position_preditor.parameters(), 0.5)
         self.optimizer_agent_position_preditor.step()

@@ -113,6 +113,14 @@ class VecPPOTrainer:
                                        step0=self.env_steps // self.N, max_goals=max_goals)
         return self.her
 
+    def sample_goal(self, t_idx, n_idx, goal2, done):
+        """Hook: per-sample goal record carried through targets / update (default: the 2-d goal itself)."""
+        return goal2
+
+    def goal_input(self, goal, after):
+        """Hook: what the networks get as goal before / after the step, from a sample_goal() record."""
+        return goal
+
     def _values(self, t_idx, n_idx, goal):
         """critic(s, g) and critic(s', g) of samples (t, n) with per-sample goals, in chunks."""
         total = t_idx.numel()
@@ -122,9 +130,11 @@ class VecPPOTrainer:
         for i in range(0, total, self.value_chunk):
             sl = slice(i, min(total, i + self.value_chunk))
             s0, p0 = self._stacks(t_idx[sl], n_idx[sl], after=False)
-            v[sl] = self.agent.critic_value(self.agent.policy_input(s0), p0, goal[sl]).view(-1)
+            v[sl] = self.agent.critic_value(self.agent.policy_input(s0), p0,
+                                            self.goal_input(goal[sl], False)).view(-1)
             s1, p1 = self._stacks(t_idx[sl], n_idx[sl], after=True)
-            nv[sl] = self.agent.critic_value(self.agent.policy_input(s1), p1, goal[sl]).view(-1)
+            nv[sl] = self.agent.critic_value(self.agent.policy_input(s1), p1,
+                                             self.goal_input(goal[sl], True)).view(-1)
         return v, nv
 
     @torch.no_grad()
@@ -132,8 +142,8 @@ class VecPPOTrainer:
         T, N = self.T, self.N
         total = T * N
         idx = torch.arange(total, device=self.device)
-        v, nv = self._values(idx // N, idx % N, self.goal1.expand(total, 2))
         done = (self.term | self.trunc).contiguous()
+        v, nv = self._values(idx // N, idx % N, self.sample_goal(idx // N, idx % N, self.goal1.expand(total, 2), done.view(-1)))
         adv, target, ret = ppo_ops.gae(self.reward, v.view(T, N), nv.view(T, N), done, gamma=self.agent.gamma,
                                        lam=self.agent.gae_lambda, use_done_mask=self.agent.use_done_mask)
         critic_target = target if self.agent.gae_lambda == 0.0 else ret
@@ -142,7 +152,7 @@ class VecPPOTrainer:
             # relabelled records: the reference's one-step target with the relabelled goal and reward (PPO.py:112-114)
             assert self.agent.gae_lambda == 0.0 and not self.agent.use_done_mask, "HER records use the TD(0) targets"
             h = self.her
-            hv, hnv = self._values(h["t"], h["n"], h["goal"])
+            hv, hnv = self._values(h["t"], h["n"], self.sample_goal(h["t"], h["n"], h["goal"], h["done"]))
             H = hv.numel()
             hadv, htarget, _ = ppo_ops.gae(h["reward"].view(1, H), hv.view(1, H), hnv.view(1, H), None,
                                            gamma=self.agent.gamma, lam=0.0, use_done_mask=False)
@@ -159,11 +169,12 @@ class VecPPOTrainer:
         total = adv.numel()                                           # rollout samples + relabelled records
         base = torch.arange(T * N, device=self.device)
         smp_t, smp_n = (base // N).int(), (base % N).int()
-        smp_goal = self.goal1.expand(T * N, 2)
+        smp_goal = self.sample_goal(smp_t, smp_n, self.goal1.expand(T * N, 2), (self.term | self.trunc).view(-1))
         if total > T * N:
-            smp_t = torch.cat([smp_t, self.her["t"]])
-            smp_n = torch.cat([smp_n, self.her["n"]])
-            smp_goal = torch.cat([smp_goal, self.her["goal"]])
+            h = self.her
+            smp_goal = torch.cat([smp_goal, self.sample_goal(h["t"], h["n"], h["goal"], h["done"])])
+            smp_t = torch.cat([smp_t, h["t"]])
+            smp_n = torch.cat([smp_n, h["n"]])
         flat = smp_t.long() * N + smp_n.long()                        # action / old log-prob are those of (t, n)
         act, logp = self.action.view(-1)[flat], self.logp.view(-1)[flat]
         ag.actor.train(); ag.critic.train()
@@ -181,8 +192,8 @@ class VecPPOTrainer:
             for i in range(0, perm.numel(), self.minibatch):
                 idx = perm[i:i + self.minibatch]
                 s0, p0 = self._stacks(smp_t[idx], smp_n[idx], after=False)
-                la, lv = ag.minibatch_step(s0, p0, smp_goal[idx], act[idx], logp[idx].view(-1, 1),
-                                           adv[idx].view(-1, 1), target[idx].view(-1, 1))
+                la, lv = ag.minibatch_step(s0, p0, self.goal_input(smp_goal[idx], False), act[idx],
+                                           logp[idx].view(-1, 1), adv[idx].view(-1, 1), target[idx].view(-1, 1))
         if ag.use_lr_decay:
             ag.scheduler_actor.step(); ag.scheduler_critic.step()
         self.her = None

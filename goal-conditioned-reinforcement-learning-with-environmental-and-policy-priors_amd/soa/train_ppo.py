@@ -43,6 +43,7 @@ def build_parser():
                    help="GEMM dtype of the actor-critic (bf16 = torch.autocast, no parity claim; fp32 = reference)")
     p.add_argument("--frame_codes", action="store_true", help="store rollout frames as uint8 codes (4x smaller, exact)")
     p.add_argument("--k_epochs", type=int, default=10)
+    p.add_argument("--k_epochs_orientation", type=int, default=50, help="SoA: epochs of the orientation head per update")
     p.add_argument("--gae_lambda", type=float, default=0.0)
     p.add_argument("--normalize_adv", action="store_true")
     p.add_argument("--predictor_file", default=None, help="checkpoint with model_encoder / model_decoder / "
@@ -50,7 +51,7 @@ def build_parser():
     return p
 
 
-def main(argv=None, predictor=False):
+def main(argv=None, predictor=False, soa=False):
     args = build_parser().parse_args(argv)
     from .. import dist as twdist
     from ..engine import TwoarmyEngine
@@ -65,28 +66,39 @@ def main(argv=None, predictor=False):
     device = torch.device("cuda", local_rank % max(1, torch.cuda.device_count())) if world > 1 else torch.device(args.cuda)
     torch.cuda.set_device(device)
 
-    if predictor:
+    if soa:
+        from .agent.Self_orientation_agent import self_orinetation_agent
+        from .soa_vec import VecSoATrainer
+        agent = self_orinetation_agent(log_root=args.log_dir)
+        agent.K_epochs_pre_agent_position = args.k_epochs_orientation
+        if args.predictor_file:
+            agent.load_world_model(torch.load(args.predictor_file, map_location="cpu", weights_only=True))
+    elif predictor:
         from .agent.PPO_Predictor import ppo_predictor
         agent = ppo_predictor(log_root=args.log_dir)
         if args.predictor_file:
             agent.load_world_model(torch.load(args.predictor_file, map_location="cpu", weights_only=True))
     else:
         agent = PPO(log_root=args.log_dir)
-    agent.name = "%s_%s_%sseed_" % ("ppo_predictor" if predictor else "ppo", args.env, seed)
+    agent.name = "%s_%s_%sseed_" % ("soa" if soa else ("ppo_predictor" if predictor else "ppo"), args.env, seed)
     agent.gamma, agent.K_epochs = args.gamma, args.k_epochs
     agent.gae_lambda, agent.use_done_mask, agent.normalize_adv = args.gae_lambda, args.gae_lambda > 0, args.normalize_adv
     agent.sample_seed = (seed or 0) + 7919 * rank
     agent.amp_dtype = torch.bfloat16 if args.amp == "bf16" else None
     agent.to(device)
     twdist.broadcast_parameters([agent.actor, agent.critic] +
-                                ([agent.encoder, agent.decoder, agent.predictor] if predictor else []))
+                                ([agent.encoder, agent.decoder, agent.predictor] if (predictor or soa) else []) +
+                                ([agent.agent_position_preditor] if soa else []))
     if world > 1:
         agent.grad_sync = twdist.GradBucket(list(agent.actor.parameters()) + list(agent.critic.parameters()))
+        if soa:                                  # the orientation head has its own optimiser step, hence its own bucket
+            agent.grad_sync_orient = twdist.GradBucket(list(agent.agent_position_preditor.parameters()))
 
     lo, hi = twdist.shard_range(args.num_envs, rank, world)
     variant = 4 if args.env.endswith("v4") else 6
     engine = TwoarmyEngine(variant, hi - lo, 17, device=device, seed=seed or 0, env_id0=lo)
-    trainer = VecPPOTrainer(agent, engine, args.rollout_steps, args.minibatch, frame_codes=args.frame_codes)
+    Trainer = VecSoATrainer if soa else VecPPOTrainer
+    trainer = Trainer(agent, engine, args.rollout_steps, args.minibatch, frame_codes=args.frame_codes)
     her = str(args.her).lower() not in ("false", "0", "no")
     score = 0.0
     for u in range(args.updates):

@@ -53,3 +53,79 @@ def test_act_batch_soa_semantics():
     assert torch.allclose(logp, want, atol=1e-5)
     act, lp, fx, fy = agent.select_action(b["s"][0][:5], b["p"][0][:5], b["g"][0], dev)
     assert 0 <= act < 5 and -3 <= fx <= 3 and -3 <= fy <= 3 and lp <= 0.0
+
+
+def test_vectorised_soa_trainer_equals_window_records():
+    """The index arithmetic of VecSoATrainer (f of the next step, 3-step displacement clamped at the episode end)
+    reproduces the reference's 9-frame window records (train_SoA.py:134-183) built literally from the same rollout."""
+    from twoarmy_amd.engine import TwoarmyEngine
+    from twoarmy_amd.soa.soa_vec import VecSoATrainer
+    torch.manual_seed(2)
+    N, T = 40, 120
+    eng = TwoarmyEngine(6, N, 17, seed=9981)
+    agent = seeded_agent()
+    tr = VecSoATrainer(agent, eng, rollout_steps=T, minibatch=512)
+    uni = torch.rand(T + 1, N, 3, device=tr.device)
+    tr.collect(uniforms=uni)
+    torch.cuda.synchronize()
+    frames, pos = tr.frames.cpu().numpy(), tr.pos.cpu().numpy()
+    fut, act = tr.future.cpu().numpy(), tr.action.cpu().numpy()
+    term, trunc = tr.term.cpu().numpy() != 0, tr.trunc.cpu().numpy() != 0
+    init_f, init_p = tr.init_frame.cpu().numpy(), np.array([15.0, 3.0], np.float32)
+    # literal 9-deep windows per env, including the four terminal shifts; keyed by the acting step of the record
+    rec = {}
+    for n in range(N):
+        s9 = np.tile(init_f, (9, 1)); p9 = np.tile(init_p, (9, 1)); f5 = np.zeros((5, 2)); k = 0; steps = []
+        for t in range(T):
+            s9 = np.append(np.delete(s9, 0, 0), [frames[t + 4, n]], 0)
+            p9 = np.append(np.delete(p9, 0, 0), [pos[t + 4, n]], 0)
+            f5 = np.append(np.delete(f5, 0, 0), [fut[t, n]], 0)
+            steps.append(t); k += 1
+            if k > 4:
+                rec[(steps[-5], n)] = (s9.copy(), p9.copy(), f5.copy())
+            if term[t, n] or trunc[t, n]:
+                for sh in range(4):
+                    s9 = np.append(np.delete(s9, 0, 0), [frames[t + 4, n]], 0)
+                    p9 = np.append(np.delete(p9, 0, 0), [pos[t + 4, n]], 0)
+                    f5 = np.append(np.delete(f5, 0, 0), [fut[t, n]], 0)
+                    if k + sh + 1 > 4:
+                        rec[(steps[-4 + sh] if len(steps) >= 4 - sh else None, n)] = (s9.copy(), p9.copy(), f5.copy())
+                s9 = np.tile(init_f, (9, 1)); p9 = np.tile(init_p, (9, 1)); f5 = np.zeros((5, 2)); k = 0; steps = []
+    rec.pop((None, 0), None)
+    keys = [k for k in rec if k[0] is not None]
+    assert len(keys) > 1000
+    t_idx = torch.tensor([k[0] for k in keys], device=tr.device)
+    n_idx = torch.tensor([k[1] for k in keys], device=tr.device)
+    s0, p0 = tr._stacks(t_idx.int(), n_idx.int(), after=False)
+    s1, p1 = tr._stacks(t_idx.int(), n_idx.int(), after=True)
+    done = ((tr.term | tr.trunc) != 0)[t_idx, n_idx]
+    g6 = tr.sample_goal(t_idx, n_idx, tr.goal1.expand(len(keys), 2), done)
+    S = np.stack([rec[k][0] for k in keys]); P = np.stack([rec[k][1] for k in keys]); F = np.stack([rec[k][2] for k in keys])
+    assert np.array_equal(s0.cpu().numpy(), S[:, 0:4]) and np.array_equal(s1.cpu().numpy(), S[:, 1:5])
+    assert np.array_equal(p0.cpu().numpy(), P[:, 0:4]) and np.array_equal(p1.cpu().numpy(), P[:, 1:5])
+    assert np.array_equal(g6[:, 2:4].cpu().numpy(), F[:, 0]) and np.array_equal(g6[:, 4:6].cpu().numpy(), F[:, 1])
+    # orientation targets of the successful episodes == p[:,6] - p[:,3] of their window records
+    ot, on, og, disp = tr.orientation_samples()
+    assert ot.numel() > 0
+    for t, n, d in zip(ot.tolist(), on.tolist(), disp.cpu().numpy()):
+        w = rec[(t, n)][1]
+        assert np.array_equal(d, w[6] - w[3]), (t, n)
+    assert float(disp.abs().max()) <= 3
+    # and the two learners run end to end (policy, then orientation), with hindsight records
+    agent.K_epochs, agent.K_epochs_pre_agent_position = 1, 1
+    tr.relabel()
+    la, lv = tr.update()
+    assert np.isfinite(float(la)) and np.isfinite(float(lv)) and np.isfinite(float(tr.last_orientation_loss))
+    pending = tr.pending_future.clone()
+    tr.carry_over()
+    tr.collect()
+    assert torch.equal(tr.future[0], pending)          # the draw made for the state after the last step is the one used
+    eng.close()
+
+
+def test_train_soa_entry_point_smoke():
+    from twoarmy_amd.soa import train_SoA
+    tr = train_SoA.main(["--env", "MiniGrid-twoarmy-17x17-v4", "--num_envs", "32", "--rollout_steps", "60",
+                         "--minibatch", "256", "--updates", "2", "--k_epochs", "1", "--k_epochs_orientation", "1",
+                         "--cuda", "cuda:0"])
+    assert tr.env_steps == 2 * 60 * 32 and tr.agent.agent_position_preditor.Px.out_features == 7
