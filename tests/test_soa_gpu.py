@@ -104,16 +104,32 @@ def test_vectorised_soa_trainer_equals_window_records():
     assert np.array_equal(s0.cpu().numpy(), S[:, 0:4]) and np.array_equal(s1.cpu().numpy(), S[:, 1:5])
     assert np.array_equal(p0.cpu().numpy(), P[:, 0:4]) and np.array_equal(p1.cpu().numpy(), P[:, 1:5])
     assert np.array_equal(g6[:, 2:4].cpu().numpy(), F[:, 0]) and np.array_equal(g6[:, 4:6].cpu().numpy(), F[:, 1])
-    # orientation targets of the successful episodes == p[:,6] - p[:,3] of their window records
+    # orientation targets of successful episodes == p[:,6] - p[:,3] of their window records (the seeded policy never
+    # reaches the goal in 120 steps, so every finished episode is declared a success for this check)
+    real_term = tr.term.clone()
+    tr.term.copy_(tr.term | tr.trunc)
     ot, on, og, disp = tr.orientation_samples()
-    assert ot.numel() > 0
+    tr.term.copy_(real_term)
+    assert ot.numel() > 500 and float(disp.abs().max()) <= 3
     for t, n, d in zip(ot.tolist(), on.tolist(), disp.cpu().numpy()):
         w = rec[(t, n)][1]
         assert np.array_equal(d, w[6] - w[3]), (t, n)
-    assert float(disp.abs().max()) <= 3
+    # hindsight records of the unsuccessful episodes: displacement clamped at the relabelled end of each prefix
+    h = tr.relabel()
+    ot, on, og, disp = tr.orientation_samples()
+    ht, hn, hd, hg = (h[k].cpu().numpy() for k in ("t", "n", "done", "goal"))
+    assert ot.numel() == ht.size > 0 and np.array_equal(og.cpu().numpy(), hg)
+    age = tr.age.cpu().numpy()
+
+    def state_pos(sidx, n):                     # position of the state before step sidx
+        return init_p if age[sidx, n] == 0 else pos[sidx + 3, n]
+    ends = np.flatnonzero(hd)
+    for i, (t, n) in enumerate(zip(ht, hn)):
+        u = ht[ends[np.searchsorted(ends, i)]]
+        want = pos[min(t + 3, u + 1) + 3, n] - state_pos(t, n)
+        assert np.array_equal(disp[i].cpu().numpy(), want), (i, t, n, u)
     # and the two learners run end to end (policy, then orientation), with hindsight records
     agent.K_epochs, agent.K_epochs_pre_agent_position = 1, 1
-    tr.relabel()
     la, lv = tr.update()
     assert np.isfinite(float(la)) and np.isfinite(float(lv)) and np.isfinite(float(tr.last_orientation_loss))
     pending = tr.pending_future.clone()
