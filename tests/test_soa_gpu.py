@@ -124,10 +124,11 @@ def test_vectorised_soa_trainer_equals_window_records():
     def state_pos(sidx, n):                     # position of the state before step sidx
         return init_p if age[sidx, n] == 0 else pos[sidx + 3, n]
     ends = np.flatnonzero(hd)
+    disp_h = disp.cpu().numpy()
     for i, (t, n) in enumerate(zip(ht, hn)):
         u = ht[ends[np.searchsorted(ends, i)]]
         want = pos[min(t + 3, u + 1) + 3, n] - state_pos(t, n)
-        assert np.array_equal(disp[i].cpu().numpy(), want), (i, t, n, u)
+        assert np.array_equal(disp_h[i], want), (i, t, n, u)
     # and the two learners run end to end (policy, then orientation), with hindsight records
     agent.K_epochs, agent.K_epochs_pre_agent_position = 1, 1
     la, lv = tr.update()
