@@ -145,7 +145,7 @@ def test_trainer_with_device_her_records():
     eng = TwoarmyEngine(4, N, 17, seed=SEED)
     agent = PPO()
     agent.K_epochs = 1
-    tr = VecPPOTrainer(agent, eng, rollout_steps=T, minibatch=2048)
+    tr = VecPPOTrainer(agent, eng, rollout_steps=T, minibatch=2048, value_chunk=2048)
     tr.collect()
     h = tr.relabel()
     H = int(h["t"].numel())
@@ -165,7 +165,8 @@ def test_trainer_with_device_her_records():
         nv = agent.critic(agent.policy_input(s1), p1, h["goal"]).view(-1)
         want_t = h["reward"] + agent.gamma * nv
     assert torch.allclose(target[T * N:], want_t, atol=1e-5) and torch.allclose(adv[T * N:], want_t - v, atol=1e-5)
-    la, lv = tr.update()
+    total = T * N + H                           # whole minibatches only: every distinct batch size costs a MIOpen search
+    la, lv = tr.update(permutations=[torch.randperm(total)[:total // 2048 * 2048]])
     assert np.isfinite(float(la)) and np.isfinite(float(lv)) and tr.her is None
     assert tr.her_switch(True, 0.2) is False and tr.her_switch(False, -0.1) is True and tr.her_switch(False, 0.05) is False
     eng.close()
@@ -174,12 +175,12 @@ def test_trainer_with_device_her_records():
 def test_train_ppo_entry_point_smoke():
     from twoarmy_amd.soa import train_ppo
     tr = train_ppo.main(["--env", "MiniGrid-twoarmy-17x17-v4", "--num_envs", "64", "--rollout_steps", "16",
-                         "--minibatch", "256", "--updates", "2", "--k_epochs", "1", "--cuda", "cuda:0"])
+                         "--minibatch", "256", "--updates", "2", "--k_epochs", "1", "--her", "False", "--cuda", "cuda:0"])
     assert tr.env_steps == 2 * 16 * 64
 
 
 def test_train_ppo_predictor_entry_point_smoke():
     from twoarmy_amd.soa import train_ppo_predictor
     tr = train_ppo_predictor.main(["--env", "MiniGrid-twoarmy-17x17-v4", "--num_envs", "32", "--rollout_steps", "8",
-                                   "--minibatch", "128", "--updates", "1", "--k_epochs", "1", "--cuda", "cuda:0"])
+                                   "--minibatch", "128", "--updates", "1", "--k_epochs", "1", "--her", "False", "--cuda", "cuda:0"])
     assert tr.env_steps == 8 * 32 and tr.agent.actor.bone1.cnn_base[0].weight.shape[1] == 8
