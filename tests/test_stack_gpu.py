@@ -131,7 +131,8 @@ def test_frame_codes_trainer_is_bit_identical():
         eng.close()
     a, b = res
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
-    assert abs(a[3] - b[3]) <= 1e-6 and abs(a[4] - b[4]) <= 1e-6       # identical inputs; conv backward may reorder sums
+    # identical inputs to both updates; MIOpen's conv backward accumulates in a run-dependent order (1.6e-6 seen)
+    assert abs(a[3] - b[3]) <= 1e-5 and abs(a[4] - b[4]) <= 1e-5
 
 
 def test_trainer_with_device_her_records():
