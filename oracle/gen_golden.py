@@ -5,7 +5,7 @@ TEST INFRASTRUCTURE ONLY.  Imports /root/reference through oracle/ref_harness.py
 classes with scripted / seeded inputs and writes small .npz fixtures into tests/golden/.
 Only data (inputs + the reference's outputs) is written; no reference source text is stored.
 
-  python oracle/gen_golden.py [traces] [views] [her] [ppo] [predictor] [occlusion] [mgstep] [soa]     (default: all)
+  python oracle/gen_golden.py [traces] [views] [her] [ppo] [predictor] [occlusion] [mgstep] [soa] [pretrain]     (default: all)
 
 The random draws of Twoarmy (np.random.choice calls in twoarmy_v{4,6}.py) are replaced by the
 engine's counter-based Philox words (oracle/philox.py) through ref_harness.patched_choice, so
@@ -607,6 +607,68 @@ def gen_soa():
           "-> %s (%.1f KB)" % (path_out, os.path.getsize(path_out) / 1024))
 
 
+# ----------------------------------------------------------------------------- offline predictor pipeline
+def gen_pretrain():
+    """soa/agent/encoder_LSTM_decoder.py: update_encoder_decoder (:95-180) and update_predictor (:182-295) on a small
+    buffer of 9-frame window records -- per-update train / validation losses with lr 5e-4 as train_encoder_decoder.py
+    :113-114 sets it, 2 epochs, batch 8, in-process DataLoader."""
+    import torch
+    env_buffer, _ = rh.soa_modules()
+    from agent import encoder_LSTM_decoder as eld
+    eld.savetxt = lambda *a, **k: None                     # the loops dump csv files to an absolute home path
+    eld.tqdm = lambda x, *a, **k: x
+    out = {}
+    buf = collect_buffer(env_buffer, "v4", 160, seed=8)
+    b = buf.buffer
+    frames = np.concatenate([b['s'][0][:4], b['s'][:, 4]]).astype(np.float64)      # consecutive frames of the random policy
+    B = 48
+    pre_t = np.dtype([('s', np.float64, (9, 289)), ('a', np.int64, (5, 1)), ('p', np.float64, (9, 2)), ('g', np.float64, (2,)),
+                      ('r', np.float64, (5, 1)), ('d', np.int64, (5, 1)), ('a_logp', np.float64, (5, 1))])
+    pb = np.zeros(B, dtype=pre_t)
+    for i in range(B):
+        pb['s'][i] = frames[3 * i:3 * i + 9]
+    out["buf_s"] = pb['s'].astype(np.float32)
+    torch.manual_seed(SEED)
+    m = eld.encoder_lstm_decoder()
+    for tag, net in (("encoder", m.encoder), ("decoder", m.decoder)):
+        out["init_%s_sum" % tag] = np.array([x[2] for x in param_stats(net)])
+    for i, net in enumerate((m.encoder, m.decoder)):
+        net.load_state_dict(det_weights_v2(net, 31 + i))
+    lstm_sd = {}
+    for k, (name, prm) in enumerate(m.predictor.state_dict().items()):
+        n = prm.numel()
+        lstm_sd[name] = torch.tensor((0.03 * np.sin(0.37 * np.arange(n, dtype=np.float64) + 1.3 * k)).reshape(tuple(prm.shape)),
+                                     dtype=prm.dtype)
+    m.predictor.load_state_dict(lstm_sd)
+    dev = torch.device("cpu")
+    m.encoder.device = m.predictor.device = dev
+    m.batch_size, m.num_workers, m.num_episodes_en_de, m.num_episodes_pre = 8, 0, 2, 2
+    m.name = "golden"
+    m.save_param = lambda *a, **k: None
+    m.save_param_encoder_decoder = lambda *a, **k: None
+    adam = lambda net: torch.optim.Adam(net.parameters(), lr=5e-04, betas=(0.9, 0.98), eps=1e-09)   # noqa: E731
+    m.optimizer_encoder, m.optimizer_decoder, m.optimizer_predictor = adam(m.encoder), adam(m.decoder), adam(m.predictor)
+    step = lambda o: torch.optim.lr_scheduler.StepLR(o, step_size=1, gamma=0.9)                      # noqa: E731
+    m.scheduler_encoder, m.scheduler_decoder, m.scheduler_predictor = (step(m.optimizer_encoder), step(m.optimizer_decoder),
+                                                                       step(m.optimizer_predictor))
+    pb32 = np.zeros(B, dtype=np.dtype([('s', np.float32, (9, 289))]))
+    pb32['s'] = pb['s']
+    torch.manual_seed(111)
+    m.update_encoder_decoder(pb32, dev)
+    out["ed_train"] = np.array([v for _, v in m.en_de_writer.scalars["loss/en_de_train_loss_update"]])
+    out["ed_val"] = np.array([v for _, v in m.en_de_writer.scalars["loss/en_de_value_loss_update"]])
+    torch.manual_seed(222)
+    m.update_predictor(pb32, dev)
+    out["pre_train"] = np.array([v for _, v in m.writer.scalars["loss/pre_train_loss_update"]])
+    out["pre_val"] = np.array([v for _, v in m.writer.scalars["loss/pre_value_loss_update"]])
+    out["final_encoder_sum"] = np.array([x[2] for x in param_stats(m.encoder)])
+    out["final_predictor_sum"] = np.array([float(v.double().sum()) for v in m.predictor.state_dict().values()])
+    path_out = os.path.join(GOLD, "pretrain.npz")
+    np.savez_compressed(path_out, **out)
+    print("pretrain: en/de", out["ed_train"][:3], out["ed_val"][:2], "predictor", out["pre_train"][:3], out["pre_val"][:2],
+          "-> %s (%.1f KB)" % (path_out, os.path.getsize(path_out) / 1024))
+
+
 # ----------------------------------------------------------------------------- general MiniGrid views (SURVEY 8 f2)
 def gen_occlusion():
     """MiniGridEnv.gen_obs / gen_obs_grid with see_through_walls False and True on random W x H grids holding
@@ -731,7 +793,7 @@ def gen_mgstep():
     print("mgstep: %d cases -> %s (%.1f KB)" % (ncase, path_out, os.path.getsize(path_out) / 1024))
 
 
-STAGES = {"traces": gen_traces, "views": gen_views, "ppo": gen_ppo, "her": gen_her, "predictor": gen_predictor, "occlusion": gen_occlusion, "mgstep": gen_mgstep, "soa": gen_soa}
+STAGES = {"traces": gen_traces, "views": gen_views, "ppo": gen_ppo, "her": gen_her, "predictor": gen_predictor, "occlusion": gen_occlusion, "mgstep": gen_mgstep, "soa": gen_soa, "pretrain": gen_pretrain}
 
 
 def main(argv):
