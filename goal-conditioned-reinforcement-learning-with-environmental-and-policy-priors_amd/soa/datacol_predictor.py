@@ -78,10 +78,11 @@ def collect_windows(engine, n_records, rollout_steps=128):
                                  init_frame)
         k = min(n_records - filled, int(w["t"].numel()))
         sl = slice(filled, filled + k)
-        buf["s"][sl] = w["s"][:k].double().cpu().numpy()
+        # the engine emits float32; the reference's records hold the doubles 0.9 / -0.9 / -0.5 / 0.3 and -0.01 ... 0.9
+        buf["s"][sl] = np.round(w["s"][:k].double().cpu().numpy(), 6)
         buf["p"][sl] = w["p"][:k].double().cpu().numpy()
         buf["a"][sl] = w["a"][:k].cpu().numpy()[..., None]
-        buf["r"][sl] = w["r"][:k].double().cpu().numpy()[..., None]
+        buf["r"][sl] = np.round(w["r"][:k].double().cpu().numpy(), 6)[..., None]
         buf["d"][sl] = w["d"][:k].cpu().numpy()[..., None]
         buf["g"][sl] = GOAL_YX
         filled += k
