@@ -46,6 +46,29 @@ def traffic_from_profile(variant, n_envs, rollout_t, view):
         return json.load(f)["traffic_bytes_per_launch"]
 
 
+def usable_cores():
+    """Host cores this process may really use: the affinity mask, cut down by a cgroup CPU quota when there is one
+    (the GPU boxes expose every core in the mask but schedule a share of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    per = int(f.read().split()[0])
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return min(n, 64)                      # 4096 envs: beyond 64 threads a shard is < 64 envs and threads only contend
+
+
 def cpu_baseline(variant, n_envs, view, seconds=10.0):
     """CPU oracle ("port": oracle/twoarmy_oracle.c) on a bounded sample of the same workload: the same 4096 envs
     stepped with the same Philox action stream and auto-reset, sharded over every host core this process may use
@@ -53,7 +76,7 @@ def cpu_baseline(variant, n_envs, view, seconds=10.0):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import twoarmy_oracle as orc
     orc.lib()
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = usable_cores()
     steps1, dt1 = orc.timed_rollout(variant, n_envs, 4.0, SEED, view=view, threads=1)
     steps, dt = orc.timed_rollout(variant, n_envs, seconds, SEED, view=view, threads=cores)
     return {"value": steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
