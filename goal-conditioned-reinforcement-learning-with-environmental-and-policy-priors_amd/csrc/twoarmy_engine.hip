@@ -998,6 +998,15 @@ __global__ __launch_bounds__(64, (E == 1 ? 4 : 2)) void tw_rollout_kernel(Params
 constexpr int PG = 16;          // envs per workgroup
 constexpr int PWAVES = 16;      // waves per workgroup
 constexpr int PCH = 128;        // steps per ring chunk
+// env-steps one emission wave takes per draw from the task counter.  1: the 16 waves of a workgroup then write 16
+// neighbouring rows of the same step at any time.  With 8 (one wave streaming 16 KB on its own) the same stores ran
+// 5-17 % slower on every box tried, and a store-only replica of the pattern (tools/store_pattern_probe.hip) drops
+// from ~6.3 to ~4.3 TB/s: the kernel is bound by the store path, not by issue (all compute without the stores: 99 us
+// of 239).
+#ifndef TW_PGRP
+#define TW_PGRP 1
+#endif
+constexpr int PGRP = TW_PGRP;
 constexpr uint32_t REC_VALID = 0x80000000u;
 
 struct Dyn { int b0, pone, i1, i2, patrol, o1y0, o2x0; };
@@ -1297,28 +1306,30 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
             if (lane == 0 && blockIdx.x < 64) g_stamp[blockIdx.x][0] = pst_l;
 #endif
         }
-        // ================= EMIT: pull groups of 8 (step, env) tasks
-        const int ngroups = len * (PG / 8);
+        // ================= EMIT: pull groups of PGRP (step, env) tasks
+        const int ngroups = len * (PG / PGRP);
         while (true) {
             int kg = 0;
             if (lane == 0) kg = atomicAdd(const_cast<int *>(&ctrl[1]), 1);
             kg = __builtin_amdgcn_readfirstlane(kg);
             if (kg >= ngroups) break;
-            const int tl = kg / (PG / 8), e0 = (kg - tl * (PG / 8)) * 8;
-            // lanes 0..7 poll their record until the logic wave has published it (valid bit in the same word)
+            const int tl = kg / (PG / PGRP), e0 = (kg - tl * (PG / PGRP)) * PGRP;
+            // lanes 0..PGRP-1 poll their record until the logic wave has published it (valid bit in the same word);
+            // the wave that draws a step's first group polls all PG records and writes the step's scalar outputs
+            const int npoll = e0 == 0 ? PG : PGRP;
             uint32_t rv = REC_VALID;
             PSTAMP(pst_t0);
             while (true) {
-                if (lane < 8) rv = const_cast<volatile uint32_t *>(ring)[tl * PG + e0 + lane];
+                if (lane < npoll) rv = const_cast<volatile uint32_t *>(ring)[tl * PG + e0 + lane];
                 if (__ballot((rv & REC_VALID) == 0u) == 0ull) break;
                 __builtin_amdgcn_s_sleep(1);
             }
             PSTAMP(pst_t1);
 #ifdef TW_STAMP
-            pst_poll += pst_t1 - pst_t0; pst_tasks += 8;
+            pst_poll += pst_t1 - pst_t0; pst_tasks += PGRP;
 #endif
-            if (lane < 8 && n0 + e0 + lane < N) {      // scalar outputs of the 8 env-steps: one lane each, contiguous rows
-                const size_t srow = (size_t)(c0 + tl) * N + n0 + e0 + lane;
+            if (e0 == 0 && lane < PG && n0 + lane < N) {   // scalar outputs of the step's PG env-steps: one lane each, contiguous
+                const size_t srow = (size_t)(c0 + tl) * N + n0 + lane;
                 p.reward[srow] = reward_value((int)((rv >> 25) & 7u));
                 p.term[srow] = (uint8_t)((rv >> 28) & 1u);
                 p.trunc[srow] = (uint8_t)((rv >> 29) & 1u);
@@ -1328,7 +1339,7 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
             uint8_t *obs_g = p.obs + grow * (size_t)p.obs_pitch;
             float *mat_g = p.matrix + grow * (size_t)p.mat_pitch;
 #pragma unroll 1
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < PGRP; ++j) {
                 if (n0 + e0 + j >= N) break;
                 const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)rv, j);
                 const int ax = r & 31, ay = (r >> 5) & 31;

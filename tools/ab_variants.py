@@ -13,16 +13,20 @@ from twoarmy_amd import _lib, engine as eng_mod  # noqa
 
 T, N = 128, 4096
 names = sys.argv[1:] or ["std"]
-engines = {}
+engines = []
 base = _lib.LIB_PATH
 for nm in names:
     _lib._lib = None
     _lib.LIB_PATH = base if nm == "std" else os.path.join(os.path.dirname(base), "libtwoarmy_hip_%s.so" % nm)
     lib = _lib.lib()                                    # binds signatures on this handle
     e = eng_mod.TwoarmyEngine(6, N, 17, seed=9981)
-    engines[nm] = (lib, e, e.fill_actions(T), e.alloc_outputs(T))
+    engines.append((nm, lib, e, e.fill_actions(T), e.alloc_outputs(T)))
+    o = engines[-1][4]
+    print("%-8s obs %#x matrix %#x pos %#x reward %#x (matrix - obs = %d MiB + %d B)" % (
+        nm, o["obs"].data_ptr(), o["matrix"].data_ptr(), o["pos"].data_ptr(), o["reward"].data_ptr(),
+        (o["matrix"].data_ptr() - o["obs"].data_ptr()) >> 20, (o["matrix"].data_ptr() - o["obs"].data_ptr()) & 0xfffff), flush=True)
 for rnd in range(4):
-    for nm, (lib, e, acts, out) in engines.items():
+    for nm, lib, e, acts, out in engines:
         _lib._lib = lib
         ms = e.time_rollout(T, out, actions=acts, iters=20)
         print("round %d %-8s %.3f ms/launch  %.3f us/step" % (rnd, nm, ms, ms * 1e3 / T), flush=True)
