@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--mode", default="rollout", choices=["rollout", "step"],
                     help="rollout: ROLLOUT_T steps per launch (headline); step: one tw_step launch per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--placement-candidates", type=int, default=6,
+                    help="output buffer sets probed at set-up (1 = take the first allocation)")
     ap.add_argument("--matrix-codes", action="store_true",
                     help="BASELINE configs[4] variant: state matrix as uint8 codes (TW_F_MATRIX_CODE), not the headline")
     args = ap.parse_args()
@@ -125,7 +127,12 @@ def main():
 
     eng = TwoarmyEngine(variant, N, V, device=dev, seed=SEED, env_id0=rank * N)
     actions = eng.fill_actions(W + K)                      # the engine's own Philox stream, HBM-resident
-    out = eng.alloc_outputs(T, matrix_codes=args.matrix_codes)
+    placement_ms = None
+    if args.mode == "rollout" and args.placement_candidates > 1:
+        # untimed set-up: pick the HBM placement of the output streams (engine.alloc_outputs_tuned explains why)
+        out, placement_ms = eng.alloc_outputs_tuned(T, candidates=args.placement_candidates, matrix_codes=args.matrix_codes)
+    else:
+        out = eng.alloc_outputs(T, matrix_codes=args.matrix_codes)
 
     def run(t_begin, n_steps):
         t = t_begin
@@ -186,7 +193,11 @@ def main():
                        "actions": "Philox(seed=9981) policy indices 0..4 (4->done), resident in HBM",
                        "outputs_per_step": "obs u8[N,V,V,3] + state_matrix %s[N,289] + pos f32[N,2] + reward f32 + term u8 + trunc u8"
                                           % ("u8-code" if args.matrix_codes else "f32"),
-                       "parallelism": "env-sharded x%d, no collective" % world},
+                       "parallelism": "env-sharded x%d, no collective" % world,
+                       "output_placement": None if placement_ms is None else {
+                           "what": "untimed set-up: %d output buffer sets allocated, the fastest kept (HBM placement of the "
+                                   "two output streams moves the store bandwidth by up to 25 %%)" % len(placement_ms),
+                           "probe_kernel_ms": placement_ms}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)"
