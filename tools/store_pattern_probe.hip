@@ -102,6 +102,21 @@ int main() {
         }
         hipFree(slab);
     }
+    // fewer writer waves per workgroup (256 workgroups x PG=16, one row per task)
+    for (int pace : {0, 4, 16}) {
+        snprintf(name, sizeof name, "writers: 4 waves / workgroup, PG=16 G=1 pace=%d", pace);
+        timeit(name, both, [&] { hipLaunchKernelGGL(pipe_kernel<4>, dim3(N / 16), dim3(256), 0, 0, obs, mat, T, N, 16, 1, row_obs, row_mat, pace); });
+        snprintf(name, sizeof name, "writers: 8 waves / workgroup, PG=16 G=1 pace=%d", pace);
+        timeit(name, both, [&] { hipLaunchKernelGGL(pipe_kernel<8>, dim3(N / 16), dim3(512), 0, 0, obs, mat, T, N, 16, 1, row_obs, row_mat, pace); });
+        snprintf(name, sizeof name, "writers: 12 waves / workgroup, PG=16 G=1 pace=%d", pace);
+        timeit(name, both, [&] { hipLaunchKernelGGL(pipe_kernel<12>, dim3(N / 16), dim3(768), 0, 0, obs, mat, T, N, 16, 1, row_obs, row_mat, pace); });
+        snprintf(name, sizeof name, "writers: 16 waves / workgroup, PG=16 G=1 pace=%d", pace);
+        timeit(name, both, [&] { hipLaunchKernelGGL(pipe_kernel<16>, dim3(N / 16), dim3(1024), 0, 0, obs, mat, T, N, 16, 1, row_obs, row_mat, pace); });
+        snprintf(name, sizeof name, "writers: 16 waves / workgroup, PG=32 G=1 pace=%d (128 workgroups)", pace);
+        timeit(name, both, [&] { hipLaunchKernelGGL(pipe_kernel<16>, dim3(N / 32), dim3(1024), 0, 0, obs, mat, T, N, 32, 1, row_obs, row_mat, pace); });
+        snprintf(name, sizeof name, "writers: 8 waves / workgroup, PG=32 G=1 pace=%d (128 workgroups)", pace);
+        timeit(name, both, [&] { hipLaunchKernelGGL(pipe_kernel<8>, dim3(N / 32), dim3(512), 0, 0, obs, mat, T, N, 32, 1, row_obs, row_mat, pace); });
+    }
     for (int G : {1, 8}) {
         snprintf(name, sizeof name, "pipe 8 waves x 512 blocks PG=8 G=%d obs+mat", G);
         timeit(name, both, [&] { hipLaunchKernelGGL(pipe_kernel<8>, dim3(N / 8), dim3(512), 0, 0, obs, mat, T, N, 8, G > 8 ? 8 : G, row_obs, row_mat, 0); });
