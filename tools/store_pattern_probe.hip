@@ -52,7 +52,7 @@ int main() {
     const int T = 128, N = 4096;
     const int row_obs = 880, row_mat = 1168;
     uint8_t *obs, *mat;
-    CK(hipMalloc(&obs, (size_t)T * N * row_obs + 4096));
+    CK(hipMalloc(&obs, (size_t)T * N * 1024 + 4096));
     CK(hipMalloc(&mat, (size_t)T * N * 2048 + 4096));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -101,6 +101,14 @@ int main() {
             timeit(name, both, [&] { hipLaunchKernelGGL(pipe_kernel<16>, dim3(N / 16), dim3(1024), 0, 0, obs, mat, T, N, 16, 1, row_obs, row_mat, 4); });
         }
         hipFree(slab);
+    }
+    // row pitches: do line-aligned rows (896 = 7 x 128, 1280 = 10 x 128) pay for the extra bytes?
+    for (int pace : {0, 4}) {
+        const int pitches[][2] = {{880, 1168}, {896, 1168}, {896, 1280}, {1024, 1280}, {880, 1280}};
+        for (auto &pp : pitches) {
+            snprintf(name, sizeof name, "pitch obs %d mat %d, PG=16 G=1 pace=%d (time only)", pp[0], pp[1], pace);
+            timeit(name, (size_t)T * N * (pp[0] + pp[1]), [&] { hipLaunchKernelGGL(pipe_kernel<16>, dim3(N / 16), dim3(1024), 0, 0, obs, mat, T, N, 16, 1, pp[0], pp[1], pace); });
+        }
     }
     // fewer writer waves per workgroup (256 workgroups x PG=16, one row per task)
     for (int pace : {0, 4, 16}) {
