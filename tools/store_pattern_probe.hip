@@ -20,7 +20,7 @@ __global__ void fill_kernel(uint4 *dst, size_t n16) {
 // counter in step-major order; a task writes G consecutive rows of `row` bytes of each of the two streams.
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void pipe_kernel(uint8_t *obs, uint8_t *mat, int T, int N, int PG, int G, int row_obs,
-                                                          int row_mat, int pace) {
+                                                          int row_mat, int pace, int block_major = 0) {
     __shared__ int ctr;
     if (threadIdx.x == 0) ctr = 0;
     __syncthreads();
@@ -35,7 +35,8 @@ __global__ __launch_bounds__(WAVES * 64) void pipe_kernel(uint8_t *obs, uint8_t 
         k = __builtin_amdgcn_readfirstlane(k);
         if (k >= ntask) break;
         const int t = k / gps, g = k - t * gps;
-        const size_t r0 = (size_t)t * N + n0 + g * G;
+        // time-major [T][N] rows, or workgroup-major [N/PG][T][PG] rows (every workgroup streams through its own region)
+        const size_t r0 = block_major ? ((size_t)blockIdx.x * T + t) * PG + g * G : (size_t)t * N + n0 + g * G;
         if (row_obs) {
             uint8_t *d = obs + r0 * row_obs;
             for (int off = 16 * lane; off < G * row_obs; off += 1024) *reinterpret_cast<uint4 *>(d + off) = v;
@@ -109,6 +110,14 @@ int main() {
             snprintf(name, sizeof name, "pitch obs %d mat %d, PG=16 G=1 pace=%d (time only)", pp[0], pp[1], pace);
             timeit(name, (size_t)T * N * (pp[0] + pp[1]), [&] { hipLaunchKernelGGL(pipe_kernel<16>, dim3(N / 16), dim3(1024), 0, 0, obs, mat, T, N, 16, 1, pp[0], pp[1], pace); });
         }
+    }
+    for (int pace : {0, 4}) {
+        for (int G : {1, 2, 8, 16}) {
+            snprintf(name, sizeof name, "workgroup-major layout [N/16][T][16], G=%d pace=%d", G, pace);
+            timeit(name, both, [&] { hipLaunchKernelGGL(pipe_kernel<16>, dim3(N / 16), dim3(1024), 0, 0, obs, mat, T, N, 16, G, row_obs, row_mat, pace, 1); });
+        }
+        snprintf(name, sizeof name, "time-major layout [T][N], G=1 pace=%d", pace);
+        timeit(name, both, [&] { hipLaunchKernelGGL(pipe_kernel<16>, dim3(N / 16), dim3(1024), 0, 0, obs, mat, T, N, 16, 1, row_obs, row_mat, pace, 0); });
     }
     // fewer writer waves per workgroup (256 workgroups x PG=16, one row per task)
     for (int pace : {0, 4, 16}) {
