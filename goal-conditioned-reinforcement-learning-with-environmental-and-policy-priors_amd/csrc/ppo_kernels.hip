@@ -62,13 +62,14 @@ __global__ void ppo_sample_kernel(const float *__restrict__ probs, int B, const 
 }
 
 // ------------------------------------------------------------------ GAE: segmented reverse scan
-// Block = 256 threads = 4 waves, 64 envs (columns) x chunks of 64 time steps walked from T backwards.
+// Block = 256 threads = 4 waves, GN envs (columns) x chunks of 64 time steps walked from T backwards (GN = 16 for
+// N < 16384 so that a 4096-env rollout still fills 256 workgroups; 64 otherwise).
 // Lanes of a wave are TIME within one env column: A_t = d_t + c_t * A_{t+1} is the suffix composition
 // of affine maps (c, d), computed with a 6-step Kogge-Stone over __shfl_down; the running A of the
 // chunk above enters as the carry.  Tiles go through LDS so that global accesses stay coalesced.
 constexpr int GT = 64;     // time steps per chunk
-constexpr int GN = 64;     // envs per block
 
+template <int GN>          // envs per block
 __global__ __launch_bounds__(256) void ppo_gae_kernel(const float *__restrict__ reward, const float *__restrict__ value,
                                                       const float *__restrict__ next_value,
                                                       const uint8_t *__restrict__ done, float gamma, float lambda,
@@ -77,14 +78,15 @@ __global__ __launch_bounds__(256) void ppo_gae_kernel(const float *__restrict__ 
     __shared__ float sd[GT][GN + 1];
     __shared__ float sc[GT][GN + 1];
     __shared__ float carry[GN];
-    const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+    constexpr int ROWS = 256 / GN;                      // time rows loaded / stored per pass
+    const int tid = threadIdx.x, tx = tid % GN, ty = tid / GN;
     const int n = blockIdx.x * GN + tx;
     if (tid < GN) carry[tid] = 0.f;
     const int nchunks = (T + GT - 1) / GT;
     for (int ch = nchunks - 1; ch >= 0; --ch) {
         const int t0 = ch * GT;
         __syncthreads();
-        for (int r = ty; r < GT; r += 4) {
+        for (int r = ty; r < GT; r += ROWS) {
             const int t = t0 + r;
             float d = 0.f, c = 1.f;                     // identity map for rows past T
             if (t < T && n < N) {
@@ -100,8 +102,8 @@ __global__ __launch_bounds__(256) void ppo_gae_kernel(const float *__restrict__ 
             sd[r][tx] = d; sc[r][tx] = c;
         }
         __syncthreads();
-        const int wave = ty, lane = tx;                 // lane = time row inside the chunk
-        for (int e = wave * 16; e < wave * 16 + 16; ++e) {
+        const int wave = tid >> 6, lane = tid & 63;     // lane = time row inside the chunk
+        for (int e = wave * (GN / 4); e < (wave + 1) * (GN / 4); ++e) {
             float d = sd[lane][e], c = sc[lane][e];
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256) void ppo_gae_kernel(const float *__restrict__ 
             if (lane == 0) carry[e] = a0;               // only this wave touches carry[e]
         }
         __syncthreads();
-        for (int r = ty; r < GT; r += 4) {
+        for (int r = ty; r < GT; r += ROWS) {
             const int t = t0 + r;
             if (t < T && n < N) {
                 const size_t i = (size_t)t * N + n;
@@ -146,9 +148,16 @@ __global__ __launch_bounds__(256) void ppo_moments_kernel(const float *__restric
 __global__ __launch_bounds__(256) void ppo_normalise_kernel(float *__restrict__ x, int64_t n, float eps,
                                                             const double *__restrict__ ws, int nblocks) {
     __shared__ float s_mean, s_inv;
+    __shared__ double r1[256], r2[256];
+    r1[threadIdx.x] = (int)threadIdx.x < nblocks ? ws[2 * threadIdx.x] : 0.0;      // nblocks <= 256 partial sums
+    r2[threadIdx.x] = (int)threadIdx.x < nblocks ? ws[2 * threadIdx.x + 1] : 0.0;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {                                            // fixed-order tree: deterministic
+        if ((int)threadIdx.x < s) { r1[threadIdx.x] += r1[threadIdx.x + s]; r2[threadIdx.x] += r2[threadIdx.x + s]; }
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
-        double a = 0.0, b = 0.0;
-        for (int k = 0; k < nblocks; ++k) { a += ws[2 * k]; b += ws[2 * k + 1]; }   // fixed order
+        const double a = r1[0], b = r2[0];
         const double mean = a / (double)n;
         double var = n > 1 ? (b - (double)n * mean * mean) / (double)(n - 1) : 0.0;  // unbiased
         if (var < 0.0) var = 0.0;
@@ -402,18 +411,24 @@ int ppo_sample(const float *probs, int B, int A, const float *uniforms, uint64_t
 int ppo_gae(const float *reward, const float *value, const float *next_value, const uint8_t *done, float gamma,
             float lambda, int use_done_mask, int T, int N, float *adv, float *target, float *ret, void *stream) {
     if (!reward || !value || !next_value || T <= 0 || N <= 0 || (use_done_mask && !done)) return TW_E_ARG;
-    hipLaunchKernelGGL(ppo_gae_kernel, dim3((N + GN - 1) / GN), dim3(256), 0, (hipStream_t)stream, reward, value,
-                       next_value, done, gamma, lambda, use_done_mask, T, N, adv, target, ret);
+    if (N >= 16384)
+        hipLaunchKernelGGL(ppo_gae_kernel<64>, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, reward, value,
+                           next_value, done, gamma, lambda, use_done_mask, T, N, adv, target, ret);
+    else
+        hipLaunchKernelGGL(ppo_gae_kernel<16>, dim3((N + 15) / 16), dim3(256), 0, (hipStream_t)stream, reward, value,
+                           next_value, done, gamma, lambda, use_done_mask, T, N, adv, target, ret);
     return check_launch();
 }
 
 int ppo_adv_norm(float *adv, int64_t n, float eps, double *workspace, void *stream) {
     if (!adv || n <= 0 || !workspace) return TW_E_ARG;
-    int nblocks = (int)((n + 255) / 256);
-    if (nblocks > 2048) nblocks = 2048;
+    int nblocks = (int)((n + 1023) / 1024);                  // partial sums: one workgroup per CU at most
+    if (nblocks > 256) nblocks = 256;
+    int nblocks2 = (int)((n + 255) / 256);
+    if (nblocks2 > 2048) nblocks2 = 2048;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(ppo_moments_kernel, dim3(nblocks), dim3(256), 0, st, adv, n, workspace);
-    hipLaunchKernelGGL(ppo_normalise_kernel, dim3(nblocks), dim3(256), 0, st, adv, n, eps, workspace, nblocks);
+    hipLaunchKernelGGL(ppo_normalise_kernel, dim3(nblocks2), dim3(256), 0, st, adv, n, eps, workspace, nblocks);
     return check_launch();
 }
 
