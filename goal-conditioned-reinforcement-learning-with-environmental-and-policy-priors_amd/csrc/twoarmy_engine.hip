@@ -995,7 +995,7 @@ __global__ __launch_bounds__(64, (E == 1 ? 4 : 2)) void tw_rollout_kernel(Params
 // Anything outside normal play (illegal action, drifted balls, injected grids, ...) raises *p.abnormal;
 // the host always enqueues the sequential kernel behind this one, which re-runs the launch from the
 // untouched input state iff the flag is set (both write the `_out` state; the host swaps afterwards).
-constexpr int PG = 16;          // envs per workgroup
+constexpr int PG_MAX = 16;      // envs per workgroup (template parameter PG = 16, 8, 4 or 2: small batches still fill the CUs)
 constexpr int PWAVES = 16;      // waves per workgroup
 constexpr int PCH = 128;        // steps per ring chunk
 // env-steps one emission wave takes per draw from the task counter.  1: the 16 waves of a workgroup then write 16
@@ -1059,7 +1059,7 @@ __device__ __forceinline__ uint32_t pack_record(int ax, int ay, const Dyn &d, in
            ((uint32_t)(truncated != 0) << 29);
 }
 
-template <int VARIANT>
+template <int VARIANT, int PG>
 __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t pipe_lds[];
     uint32_t *img = pipe_lds;                                   // [PWAVES][ENV_WORDS]
@@ -1087,7 +1087,7 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
         mcb(my_img)[c] = c < NC ? mcode_of(mat_of_code(static_cell(c - (c / GS) * GS, c / GS))) : 0;
     const bool code_mode = (p.flags & TW_F_MATRIX_CODE) != 0;
     uint8_t *img_bytes = reinterpret_cast<uint8_t *>(my_img);
-    if (lane < REC) recs[wave * REC + lane] = (n0 + wave < N) ? p.rec[(size_t)(n0 + wave) * REC + lane] : 0;
+    if (wave < PG && lane < REC) recs[wave * REC + lane] = (n0 + wave < N) ? p.rec[(size_t)(n0 + wave) * REC + lane] : 0;
     if (tid == 0) { ctrl[0] = 0; ctrl[1] = 0; }
     if (blockIdx.x == 0 && tid == 0) *p.abnormal_other = 0;     // stream order: the previous launch's fallback is done
     __syncthreads();
@@ -1095,9 +1095,9 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
     // ---- wave e verifies env n0+e: scalar regime + planes == closed form
     {
         EnvS s;
-        load_env(s, recs + wave * REC);
+        load_env(s, recs + (wave < PG ? wave : 0) * REC);
         bool ok = true;
-        if (n0 + wave < N) {
+        if (wave < PG && n0 + wave < N) {
             ok = pipe_state_ok<V4>(s);
             Dyn d = {s.obx[0], s.pone, s.wall_i1, s.wall_i2, s.patrol, s.o1y[0], s.o2x[0]};
             const size_t gb = (size_t)(n0 + wave) * NC;
@@ -1450,7 +1450,7 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
         }
     }
     __syncthreads();
-    if (n0 + wave < N) {
+    if (wave < PG && n0 + wave < N) {
         const int32_t *r = recs + wave * REC;
         if (lane < REC) p.rec_out[(size_t)(n0 + wave) * REC + lane] = r[lane];
         Dyn fd = {r[TW_OBX], r[TW_PONE], r[TW_WALL_I1], r[TW_WALL_I2], r[TW_PATROL], r[TW_O1Y], r[TW_O2X]};
@@ -1613,7 +1613,7 @@ void launch_variant(const tw_engine *e, const Params &p, hipStream_t st) {
 }
 
 constexpr int PIPE_MIN_T = 8;
-constexpr size_t PIPE_LDS_BYTES = (size_t)(PWAVES * ENV_WORDS + PCH * PG + PG * REC + 4 + PCH * PG) * 4;   // ~117 KB
+constexpr size_t PIPE_LDS_BYTES = (size_t)(PWAVES * ENV_WORDS + PCH * PG_MAX + PG_MAX * REC + 4 + PCH * PG_MAX) * 4;   // ~117 KB
 
 int launch_sequential(const tw_engine *e, const Params &p, hipStream_t st) {
     switch (pick_envs_per_wave(e)) {
@@ -1642,9 +1642,20 @@ int launch_rollout(tw_engine *e, int T, const int32_t *actions, const uint32_t *
     p.abnormal = e->abnormal + e->parity;
     p.abnormal_other = e->abnormal + (e->parity ^ 1);
     e->parity ^= 1;
-    const int grid = (e->n_envs + PG - 1) / PG;
-    if (e->variant == 4) hipLaunchKernelGGL((tw_pipe_kernel<4>), dim3(grid), dim3(64 * PWAVES), PIPE_LDS_BYTES, st, p);
-    else hipLaunchKernelGGL((tw_pipe_kernel<6>), dim3(grid), dim3(64 * PWAVES), PIPE_LDS_BYTES, st, p);
+    // envs per workgroup: 16 from 4096 envs up; fewer for small batches so that ~256 workgroups exist (one per CU)
+    int pg = 2;
+    while (pg < PG_MAX && (e->n_envs + pg - 1) / pg > 256) pg <<= 1;
+    const int grid = (e->n_envs + pg - 1) / pg;
+#define TW_PIPE_LAUNCH(VAR, PGV) \
+    hipLaunchKernelGGL((tw_pipe_kernel<VAR, PGV>), dim3(grid), dim3(64 * PWAVES), PIPE_LDS_BYTES, st, p)
+    if (e->variant == 4) {
+        if (pg == 16) TW_PIPE_LAUNCH(4, 16); else if (pg == 8) TW_PIPE_LAUNCH(4, 8);
+        else if (pg == 4) TW_PIPE_LAUNCH(4, 4); else TW_PIPE_LAUNCH(4, 2);
+    } else {
+        if (pg == 16) TW_PIPE_LAUNCH(6, 16); else if (pg == 8) TW_PIPE_LAUNCH(6, 8);
+        else if (pg == 4) TW_PIPE_LAUNCH(6, 4); else TW_PIPE_LAUNCH(6, 2);
+    }
+#undef TW_PIPE_LAUNCH
     HIP_TRY(hipGetLastError());
     p.only_if_flagged = 1;
     int rc = launch_sequential(e, p, st);
@@ -1688,11 +1699,14 @@ int tw_create(tw_engine **out, int variant, int n_envs, int view_size, int devic
         if (me != hipSuccess) { tw_destroy(e); return hip_fail(me); }
     }
     {   // the pipelined kernel needs > 64 KB of dynamic LDS
-        hipError_t a1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&tw_pipe_kernel<4>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)PIPE_LDS_BYTES);
-        hipError_t a2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&tw_pipe_kernel<6>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)PIPE_LDS_BYTES);
-        if (a1 != hipSuccess || a2 != hipSuccess) e->pipeline = 0;
+        const void *kernels[] = {
+            reinterpret_cast<const void *>(&tw_pipe_kernel<4, 16>), reinterpret_cast<const void *>(&tw_pipe_kernel<4, 8>),
+            reinterpret_cast<const void *>(&tw_pipe_kernel<4, 4>), reinterpret_cast<const void *>(&tw_pipe_kernel<4, 2>),
+            reinterpret_cast<const void *>(&tw_pipe_kernel<6, 16>), reinterpret_cast<const void *>(&tw_pipe_kernel<6, 8>),
+            reinterpret_cast<const void *>(&tw_pipe_kernel<6, 4>), reinterpret_cast<const void *>(&tw_pipe_kernel<6, 2>)};
+        for (const void *k : kernels)
+            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PIPE_LDS_BYTES) != hipSuccess)
+                e->pipeline = 0;
     }
     Params p = base_params(e);
     hipLaunchKernelGGL(tw_reset_kernel, dim3(n_envs), dim3(64), 0, 0, p, (const uint8_t *)nullptr, 0);

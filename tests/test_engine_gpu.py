@@ -153,10 +153,12 @@ def _compare_rollout(variant, N, T, view, env0=0, chunk=None, dense=False, epw=0
 
 @pytest.mark.parametrize("variant", [6, 4])
 @pytest.mark.parametrize("N,T,view,env0,chunk", [(4096, 200, 17, 0, None), (4096, 300, 17, 0, 128), (1000, 130, 17, 77, 40),
-                                                 (17, 64, 17, 5, None), (513, 100, 7, 0, 9), (4099, 40, 9, 1 << 20, None)])
+                                                 (17, 64, 17, 5, None), (513, 100, 7, 0, 9), (4099, 40, 9, 1 << 20, None),
+                                                 (1500, 70, 17, 9, None), (2048, 130, 17, 0, 64), (300, 90, 17, 4, None)])
 def test_pipelined_rollout_vs_oracle(variant, N, T, view, env0, chunk):
-    """The pipelined kernel (closed-form logic wave + 15 emission waves per 16 envs): bit-exact vs the CPU
-    oracle, incl. ragged N, small views, chunked launches (state hand-over through the ping-pong buffers)."""
+    """The pipelined kernel (closed-form logic wave + 15 emission waves per 16 / 8 / 4 / 2 envs, chosen from the batch
+    size): bit-exact vs the CPU oracle, incl. ragged N, small views, chunked launches (state hand-over through the
+    ping-pong buffers)."""
     _compare_rollout(variant, N, T, view, env0=env0, chunk=chunk, supply_actions=True, pipeline=True)
 
 
