@@ -16,7 +16,7 @@ import os
 import statistics
 import sys
 
-KERNEL = "tw_pipe_kernel<6>"
+KERNEL = "tw_pipe_kernel<6, 16>"
 ALGORITHMIC = (4 + 17 * 17 * 3 + 289 * 4 + 8 + 4 + 1 + 1 + 2 * (289 + 289 + 48 * 4) / 128.0) * 4096 * 128
 
 
