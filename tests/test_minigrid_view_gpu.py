@@ -35,7 +35,7 @@ def test_view_kernel_matches_reference_goldens(golden_dir):
 
 
 @pytest.mark.parametrize("W,H,V,N", [(17, 17, 7, 300), (17, 17, 17, 200), (8, 30, 5, 257), (40, 40, 31, 64),
-                                      (3, 3, 3, 65), (21, 9, 11, 128), (6, 6, 1, 10)])
+                                      (3, 3, 3, 65), (21, 9, 11, 128), (6, 6, 1, 10), (10, 10, 8, 50), (12, 7, 4, 70), (9, 9, 30, 33)])
 @pytest.mark.parametrize("see_through", [False, True])
 def test_view_kernel_matches_oracle_random(W, H, V, N, see_through):
     rs = np.random.RandomState(W * 1000 + H * 10 + V)
