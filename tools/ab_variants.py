@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """A/B timing of diagnostic library builds in ONE process on ONE box (box-to-box variance is ~25 %):
 python tools/ab_variants.py std xcd nt ...   (suffixes of libtwoarmy_hip_<suffix>.so, "std" = the shipped library).
-Each variant is loaded as its own ctypes handle; rounds are interleaved."""
+Each variant is loaded as its own ctypes handle; rounds are interleaved; all variants write into the SAME output
+buffers (their HBM placement alone moves the time by up to 25 %) unless AB_SHARED_OUTPUTS=0."""
 import ctypes as C
 import os
 import sys
@@ -20,7 +21,8 @@ for nm in names:
     _lib.LIB_PATH = base if nm == "std" else os.path.join(os.path.dirname(base), "libtwoarmy_hip_%s.so" % nm)
     lib = _lib.lib()                                    # binds signatures on this handle
     e = eng_mod.TwoarmyEngine(6, N, 17, seed=9981)
-    engines.append((nm, lib, e, e.fill_actions(T), e.alloc_outputs(T)))
+    shared = engines[0][4] if engines and os.environ.get("AB_SHARED_OUTPUTS", "1") == "1" else None
+    engines.append((nm, lib, e, e.fill_actions(T), shared if shared is not None else e.alloc_outputs(T)))
     o = engines[-1][4]
     print("%-8s obs %#x matrix %#x pos %#x reward %#x (matrix - obs = %d MiB + %d B)" % (
         nm, o["obs"].data_ptr(), o["matrix"].data_ptr(), o["pos"].data_ptr(), o["reward"].data_ptr(),
