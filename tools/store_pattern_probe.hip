@@ -20,13 +20,13 @@ __global__ void fill_kernel(uint4 *dst, size_t n16) {
 // counter in step-major order; a task writes G consecutive rows of `row` bytes of each of the two streams.
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void pipe_kernel(uint8_t *obs, uint8_t *mat, int T, int N, int PG, int G, int row_obs,
-                                                          int row_mat, int pace, int block_major = 0) {
+                                                          int row_mat, int pace, int block_major = 0, int split = 0) {
     __shared__ int ctr;
     if (threadIdx.x == 0) ctr = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int n0 = blockIdx.x * PG;
-    const int gps = PG / G;
+    const int gps = (PG / G) << split;                   // split: a task writes ONE stream of its rows (twice the tasks)
     const int ntask = T * gps;
     const uint4 v = make_uint4(lane, blockIdx.x, 3, 4);
     while (true) {
@@ -34,14 +34,17 @@ __global__ __launch_bounds__(WAVES * 64) void pipe_kernel(uint8_t *obs, uint8_t 
         if (lane == 0) k = atomicAdd(&ctr, 1);
         k = __builtin_amdgcn_readfirstlane(k);
         if (k >= ntask) break;
-        const int t = k / gps, g = k - t * gps;
+        const int t = k / gps;
+        int g = k - t * gps;
+        const int which = split ? (g & 1) : 2;                   // 0 obs only, 1 matrix only, 2 both
+        g >>= split;
         // time-major [T][N] rows, or workgroup-major [N/PG][T][PG] rows (every workgroup streams through its own region)
         const size_t r0 = block_major ? ((size_t)blockIdx.x * T + t) * PG + g * G : (size_t)t * N + n0 + g * G;
-        if (row_obs) {
+        if (row_obs && which != 1) {
             uint8_t *d = obs + r0 * row_obs;
             for (int off = 16 * lane; off < G * row_obs; off += 1024) *reinterpret_cast<uint4 *>(d + off) = v;
         }
-        if (row_mat) {
+        if (row_mat && which != 0) {
             uint8_t *d = mat + r0 * row_mat;
             for (int off = 16 * lane; off < G * row_mat; off += 1024) *reinterpret_cast<uint4 *>(d + off) = v;
         }
@@ -118,6 +121,12 @@ int main() {
         }
         snprintf(name, sizeof name, "time-major layout [T][N], G=1 pace=%d", pace);
         timeit(name, both, [&] { hipLaunchKernelGGL(pipe_kernel<16>, dim3(N / 16), dim3(1024), 0, 0, obs, mat, T, N, 16, 1, row_obs, row_mat, pace, 0); });
+    }
+    for (int pace : {0, 2, 4}) {
+        snprintf(name, sizeof name, "one stream per task (split), PG=16 G=1 pace=%d", pace);
+        timeit(name, both, [&] { hipLaunchKernelGGL(pipe_kernel<16>, dim3(N / 16), dim3(1024), 0, 0, obs, mat, T, N, 16, 1, row_obs, row_mat, pace, 0, 1); });
+        snprintf(name, sizeof name, "both streams per task,          PG=16 G=1 pace=%d", pace);
+        timeit(name, both, [&] { hipLaunchKernelGGL(pipe_kernel<16>, dim3(N / 16), dim3(1024), 0, 0, obs, mat, T, N, 16, 1, row_obs, row_mat, pace, 0, 0); });
     }
     // fewer writer waves per workgroup (256 workgroups x PG=16, one row per task)
     for (int pace : {0, 4, 16}) {
