@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
@@ -98,6 +99,20 @@ int main() {
                 snprintf(name, sizeof name, "slab: obs = mat_end + %zu B, PG=16 G=%d pace=4", delta, G);
                 uint8_t *m = slab, *o = slab + mat_bytes + delta;
                 timeit(name, both, [&] { hipLaunchKernelGGL(pipe_kernel<16>, dim3(N / 16), dim3(1024), 0, 0, o, m, T, N, 16, G, row_obs, row_mat, 4); });
+            }
+        }
+        if (getenv("PROBE_DELTA_SWEEP")) {
+            hipFree(slab);
+            CK(hipMalloc(&slab, mat_bytes + obs_bytes + (272u << 20)));
+            for (size_t mb = 0; mb <= 256; mb += 2) {
+                snprintf(name, sizeof name, "sweep: obs = mat_end + %zu MiB, G=1 pace=4", mb);
+                uint8_t *m = slab, *o = slab + mat_bytes + (mb << 20);
+                timeit(name, both, [&] { hipLaunchKernelGGL(pipe_kernel<16>, dim3(N / 16), dim3(1024), 0, 0, o, m, T, N, 16, 1, row_obs, row_mat, 4); });
+            }
+            for (size_t kb = 0; kb <= 2048; kb += 64) {
+                snprintf(name, sizeof name, "sweep: obs = mat_end + %zu KiB, G=1 pace=4", kb);
+                uint8_t *m = slab, *o = slab + mat_bytes + (kb << 10);
+                timeit(name, both, [&] { hipLaunchKernelGGL(pipe_kernel<16>, dim3(N / 16), dim3(1024), 0, 0, o, m, T, N, 16, 1, row_obs, row_mat, 4); });
             }
         }
         for (int rep = 0; rep < 4; ++rep) {
