@@ -66,3 +66,24 @@ slabs = [slab_outputs(T, N) for _ in range(K)]
 for rnd in range(2):
     print("slab sets round %d: " % rnd + "  ".join("%.3f" % eng.time_rollout(T, o, actions=acts, iters=10) for o in slabs), flush=True)
 print("separate sets again: " + "  ".join("%.3f" % eng.time_rollout(T, o, actions=acts, iters=10) for o in sets), flush=True)
+
+
+# windows of ONE big allocation: are there fast and slow regions inside a single VA-contiguous slab?
+del slabs
+torch.cuda.empty_cache()
+WIN = 1280 << 20
+big = torch.empty(12 * WIN, dtype=torch.uint8, device=eng.device)
+
+
+def window_outputs(base, T, N, V=17):
+    nb, ob, mb = V * V * 3, 880, 292 * 4
+    m = big[base:base + T * N * mb].view(torch.float32).view(T, N, 292)[..., :289]
+    o0 = base + (T * N * mb + 4095) // 4096 * 4096
+    ob_t = big[o0:o0 + T * N * ob].view(T, N, ob)[..., :nb].view(T, N, V, V, 3)
+    return dict(sets[0], obs=ob_t, matrix=m)
+
+
+wins = [window_outputs(k * WIN, T, N) for k in range(12)]
+for rnd in range(2):
+    print("12 windows of one 15 GiB slab, round %d: " % rnd +
+          "  ".join("%.3f" % eng.time_rollout(T, o, actions=acts, iters=10) for o in wins), flush=True)
