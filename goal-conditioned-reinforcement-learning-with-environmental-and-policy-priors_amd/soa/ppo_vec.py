@@ -47,6 +47,7 @@ class VecPPOTrainer:
         self.pos[:4] = self.init_pos
         agent.to(d)
         self.her = None                       # relabelled index records of the current rollout (relabel())
+        self._prev = None                     # (pos, term, trunc, reward, age0) of the previous rollout
         self.her_seed = int(getattr(engine, "seed", 9981))
         self.env_steps = 0
         self.episodes_done = 0
@@ -86,8 +87,11 @@ class VecPPOTrainer:
         self.env_steps += T * N
 
     def carry_over(self):
-        """Make the last 4 frames the history of the next rollout."""
+        """Make the last 4 frames the history of the next rollout (and keep what hindsight relabelling needs of
+        this one: episodes that end in the next rollout start here)."""
         T = self.T
+        self._prev = (self.pos[4:4 + T].clone(), self.term.clone(), self.trunc.clone(), self.reward.clone(),
+                      self.age[0].clone())
         self.frames_buf[:4] = self.frames_buf[T:T + 4].clone()
         self.pos[:4] = self.pos[T:T + 4].clone()
         self.age[0] = self.age[T]
@@ -106,11 +110,26 @@ class VecPPOTrainer:
         """Buffer_gridworld.her_func (env_buffer.py:101-143) for every episode that lies inside this rollout:
         relabelled transitions are index records (t, n, goal', reward', done') produced on the device
         (ppo_her_relabel); update() then trains on the rollout plus these records, like the reference trains on
-        its ring buffer with the appended copies."""
-        T = self.T
-        self.her = ppo_ops.her_relabel(self.pos[4:4 + T], self.term, self.trunc, self.age[0].contiguous(), self.reward,
-                                       choices, seed=self.her_seed, env_id0=self.engine.env_id0,
-                                       step0=self.env_steps // self.N, max_goals=max_goals)
+        its ring buffer with the appended copies.
+
+        Episodes that began in the previous rollout are relabelled over the two-rollout window (positions, rewards and
+        done flags of the previous rollout are kept by carry_over); only their records that lie in the current rollout
+        are returned -- the earlier part of such a prefix belongs to samples whose frames are gone."""
+        T, N = self.T, self.N
+        start = self.env_steps // N - T                       # global step index of this rollout's first step
+        if self._prev is None or choices is not None:
+            self.her = ppo_ops.her_relabel(self.pos[4:4 + T], self.term, self.trunc, self.age[0].contiguous(),
+                                           self.reward, choices, seed=self.her_seed, env_id0=self.engine.env_id0,
+                                           step0=start, max_goals=max_goals)
+            return self.her
+        ppos, pterm, ptrunc, prew, page0 = self._prev
+        h = ppo_ops.her_relabel(torch.cat([ppos, self.pos[4:4 + T]]), torch.cat([pterm, self.term]),
+                                torch.cat([ptrunc, self.trunc]), page0, torch.cat([prew, self.reward]), None,
+                                seed=self.her_seed, env_id0=self.engine.env_id0, step0=start - T, max_goals=max_goals)
+        keep = h["t"] >= T
+        self.her = dict(t=(h["t"][keep] - T).contiguous(), n=h["n"][keep].contiguous(), goal=h["goal"][keep].contiguous(),
+                        reward=h["reward"][keep].contiguous(), done=h["done"][keep].contiguous())
+        self.her["counts"] = torch.bincount(self.her["n"].long(), minlength=N).int()
         return self.her
 
     def sample_goal(self, t_idx, n_idx, goal2, done):
