@@ -1,21 +1,34 @@
 #!/usr/bin/env python3
 """Headline benchmark: env-steps/sec of the batched HIP Twoarmy step engine.
 
-Workload = BASELINE.json configs[1]: MiniGrid-twoarmy-17x17-v6, 4096 envs on one MI355X, batched
-HIP step() only (obs + state matrix + reward/done written every step), auto-reset on, view 17,
+Workload (default, --mode rollout) = BASELINE.json configs[1]: MiniGrid-twoarmy-17x17-v6, 4096 envs on one
+MI355X, batched HIP step() only (obs + state matrix + reward/done written every env-step), auto-reset on, view 17,
 actions = Philox(seed 9981) policy indices resident in HBM.
 
-A "step" = one environment step of all envs of one GPU.  Steps are issued as rollouts of
-ROLLOUT_T steps per launch (tw_rollout, include/twoarmy.h) plus one remainder launch, so exactly
-K steps are timed.  With --gpus N (torch.distributed.run, one rank per GPU) every rank steps its
-own 4096 envs (env ids rank*4096..): the path shards with no data-path collective, scaling = weak.
+A bench "step" = ONE ROLLOUT LAUNCH = ROLLOUT_T (128) environment steps of all envs of one GPU (tw_rollout,
+include/twoarmy.h): `--steps K --warmup W` runs W untimed launches and then times exactly K launches, so
+value = n_gpus * envs * 128 * K / wall.  The same K launches are bracketed by events on the launch stream and
+`roofline.achieved` comes from that one region (value x bytes-per-env-step == achieved up to the host's
+barrier/sync overhead, reported as roofline.wall_over_event).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--envs 4096] [--variant v6] [--view 17]
-                  [--no-cpu-baseline] [--mode rollout|step]
+                  [--mode rollout|step|ppo] [--no-cpu-baseline]
+
+--gpus N > 1 without a torch.distributed environment: this process starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD (before anything here touches the
+GPU), relays rank 0's JSON line and exits with the child's code.  Every rank steps its own env range
+(env ids rank*envs ..): the path shards with no data-path collective, scaling = weak.  The process group is
+"nccl" (= RCCL over xGMI) with one GPU per rank; one sanity all-reduce is recorded in the output.
+
+--mode ppo: BASELINE configs[2]/[3] loop (v4 by default): each step = one PPO iteration of the rank's envs
+(128-step rollout with the actor in the loop + K-epoch update); the gradient bucket all-reduce (dist.GradBucket,
+one flattened fp32 bucket per optimiser step) is timed with events and reported per optimiser step.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,6 +38,7 @@ sys.path.insert(0, ROOT)
 ROLLOUT_T = 128
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 SEED = 9981                    # reference default, soa/train_ppo.py:25
+FWD_FLOP_PER_SAMPLE_PER_NET = 47.5e6
 
 
 def algorithmic_bytes_per_env_step(view, rollout_t, matrix_bytes=289 * 4):
@@ -39,11 +53,14 @@ def algorithmic_bytes_per_env_step(view, rollout_t, matrix_bytes=289 * 4):
 def traffic_from_profile(variant, n_envs, rollout_t, view):
     """HBM bytes per launch of the dominant kernel from the committed PMC profile of the SAME configuration
     (a bench run cannot profile itself); None when the configuration differs from the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if not (variant == "v6" and n_envs == 4096 and rollout_t == 128 and view == 17 and os.path.exists(path)):
-        return None
-    with open(path) as f:
-        return json.load(f)["traffic_bytes_per_launch"]
+    if not (variant == "v6" and n_envs == 4096 and rollout_t == 128 and view == 17):
+        return None, None
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            with open(path) as f:
+                return json.load(f)["traffic_bytes_per_launch"], "profiles/" + name
+    return None, None
 
 
 def usable_cores():
@@ -85,90 +102,130 @@ def cpu_baseline(variant, n_envs, view, seconds=10.0):
             "single_thread_value": steps1 / dt1, "host_cores_available": os.cpu_count()}
 
 
-def main():
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2560)
-    ap.add_argument("--warmup", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (rollout/ppo: launches / PPO iterations; "
+                    "step mode: single env-batch steps); default 40 / 2 / 2560")
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
-    ap.add_argument("--variant", default="v6")
+    ap.add_argument("--variant", default=None, help="v6 (default for rollout/step) or v4 (default for ppo)")
     ap.add_argument("--view", type=int, default=17)
-    ap.add_argument("--mode", default="rollout", choices=["rollout", "step"],
-                    help="rollout: ROLLOUT_T steps per launch (headline); step: one tw_step launch per step")
+    ap.add_argument("--mode", default="rollout", choices=["rollout", "step", "ppo"],
+                    help="rollout: 128 env-steps per launch (headline); step: one tw_step launch per env-step; "
+                         "ppo: rollout with the actor in the loop + PPO update, gradient all-reduce per optimiser step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--placement-candidates", type=int, default=6,
-                    help="output buffer sets probed at set-up (1 = take the first allocation)")
+    ap.add_argument("--placement-candidates", type=int, default=1,
+                    help="diagnostic: >1 probes that many torch-allocated output sets at set-up and keeps the fastest "
+                         "(the default output slab comes from the engine, tw_alloc_outputs)")
+    ap.add_argument("--torch-outputs", action="store_true",
+                    help="diagnostic: outputs from torch's caching allocator instead of the engine's slab")
     ap.add_argument("--matrix-codes", action="store_true",
                     help="BASELINE configs[4] variant: state matrix as uint8 codes (TW_F_MATRIX_CODE), not the headline")
-    args = ap.parse_args()
+    # ppo mode
+    ap.add_argument("--minibatch", type=int, default=32768)
+    ap.add_argument("--k-epochs", type=int, default=1)
+    ap.add_argument("--amp", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--her", action="store_true")
+    ap.add_argument("--predictor", action="store_true", help="ppo mode: PPO + predictor head (configs[4])")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="launcher / process-group plumbing only, no engine (for CPU-only hosts: gloo); the line "
+                         "carries value 0 and \"data\": \"rehearsal\" and is not a measurement")
+    return ap
 
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args, argv):
+    """Parent of an N-rank run: start the ranks as child processes (this process has not touched the GPU and never
+    does), relay their output, return the child's exit code."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:
+        sys.stdout.write(out)
+        sys.stdout.flush()
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+    rc = proc.wait()
+    if rc == 0 and line is not None and json.loads(line).get("n_gpus") != args.gpus:
+        print("bench.py: the ranks reported n_gpus != %d" % args.gpus, file=sys.stderr)
+        return 3
+    if rc == 0 and line is None:
+        print("bench.py: the ranks printed no result line", file=sys.stderr)
+        return 4
+    return rc
+
+
+def init_ranks(args):
+    """(rank, world, device or None, collective record).  One process per GPU; backend nccl (RCCL) when every rank has
+    its own GPU, gloo otherwise (CPU-only rehearsal, or more ranks than GPUs on a one-GPU box)."""
     import torch
     import torch.distributed as dist
-    from twoarmy_amd.engine import TwoarmyEngine
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    ngpu = torch.cuda.device_count()
+    if ngpu == 0 and not args.rehearse:
+        raise SystemExit("bench.py: no GPU visible; the engine has no CPU path (use --rehearse for the launcher only)")
+    dev = None
+    if ngpu:
+        torch.cuda.set_device(local_rank % ngpu)
+        dev = torch.device("cuda", local_rank % ngpu)
+    coll = {"backend": None, "world_size": world}
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        ngpu = torch.cuda.device_count()
-        torch.cuda.set_device(local_rank % ngpu)
         if ngpu >= world:                   # one rank per GPU: RCCL over xGMI
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:                               # rehearsal of the N>1 path on a box with fewer GPUs than ranks
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:                               # rehearsal of the N>1 path with fewer GPUs than ranks
             dist.init_process_group(backend="gloo")
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", torch.cuda.current_device())
-    variant = {"v4": 4, "v6": 6}[args.variant]
-    N, K, W, V = args.envs, args.steps, args.warmup, args.view
-    T = ROLLOUT_T if args.mode == "rollout" else 1
+        coll["backend"] = dist.get_backend()
+        one = torch.ones(1024, dtype=torch.float32, device=dev if coll["backend"] == "nccl" else "cpu")
+        dist.all_reduce(one)
+        coll["sanity_allreduce_of_ones"] = float(one[0].item())       # == world: every rank took part
+        assert one.min().item() == world == one.max().item(), "sanity all-reduce saw %s ranks" % one[0].item()
+        coll["gpus_visible_per_rank"] = ngpu
+    return rank, world, dev, coll
 
-    eng = TwoarmyEngine(variant, N, V, device=dev, seed=SEED, env_id0=rank * N)
-    actions = eng.fill_actions(W + K)                      # the engine's own Philox stream, HBM-resident
-    placement_ms = None
-    if args.mode == "rollout" and args.placement_candidates > 1:
-        # untimed set-up: pick the HBM placement of the output streams (engine.alloc_outputs_tuned explains why)
-        out, placement_ms = eng.alloc_outputs_tuned(T, candidates=args.placement_candidates, matrix_codes=args.matrix_codes)
-    else:
-        out = eng.alloc_outputs(T, matrix_codes=args.matrix_codes)
 
-    def run(t_begin, n_steps):
-        t = t_begin
-        end = t_begin + n_steps
-        while t < end:
-            tt = min(T, end - t)
-            sub = out if tt == T else {k: v[:tt] for k, v in out.items()}
-            eng.rollout(tt, sub, actions=actions[t:t + tt], autoreset=True, policy_idx=True)
-            t += tt
-
-    def barrier():
+def sync_all(dev, world):
+    import torch
+    import torch.distributed as dist
+    if dev is not None:
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    run(0, W)
-    barrier()
-    t0 = time.perf_counter()
-    run(W, K)
-    barrier()
-    dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dist.barrier()
+    if dev is not None:
+        torch.cuda.synchronize()
 
-    # --- roofline leg: the same kernel timed with HIP events on its own launch stream
-    bpe = algorithmic_bytes_per_env_step(V, T, 289 if args.matrix_codes else 289 * 4)
-    iters = max(3, min(50, K // T))
-    k_ms = eng.time_rollout(T, out, actions=actions[:T], autoreset=True, iters=iters)
-    bytes_per_launch = bpe * N * T
-    achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
-    traffic = None if args.matrix_codes else traffic_from_profile(args.variant, N, T, V)
-    torch.cuda.synchronize()
-    # write-only ceiling of this very box (report a measured device ceiling beside the vendor peak)
+
+def max_over_ranks(dt, dev, world):
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return dt
+    on_gpu = dist.get_backend() == "nccl"
+    t = torch.tensor([dt], dtype=torch.float64, device=dev if on_gpu else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def fill_ceiling_gbs(dev):
+    """Write-only ceiling of this very box (a measured device ceiling beside the vendor peak)."""
+    import torch
     buf = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
     buf.fill_(1)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -177,43 +234,232 @@ def main():
         buf.fill_(2)
     e1.record()
     torch.cuda.synchronize()
-    fill_gbs = 5 * buf.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
-    del buf
+    return 5 * buf.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
+
+def run_engine_mode(args, rank, world, dev, coll):
+    import torch
+    from twoarmy_amd.engine import TwoarmyEngine
+    vname = args.variant or "v6"
+    variant = {"v4": 4, "v6": 6}[vname]
+    N, V = args.envs, args.view
+    rollout = args.mode == "rollout"
+    T = ROLLOUT_T if rollout else 1
+    K = args.steps if args.steps is not None else (40 if rollout else 2560)
+    W = args.warmup if args.warmup is not None else (10 if rollout else 256)
+
+    eng = TwoarmyEngine(variant, N, V, device=dev, seed=SEED, env_id0=rank * N)
+    # the engine's own Philox stream, HBM-resident; launches cycle over a fixed window of it
+    n_act = min(W + K, 64) if rollout else W + K
+    actions = eng.fill_actions(n_act * T).view(n_act, T, N)
+    placement_ms = None
+    if rollout and args.placement_candidates > 1:
+        out, placement_ms = eng.alloc_outputs_tuned(T, candidates=args.placement_candidates, matrix_codes=args.matrix_codes)
+    elif args.torch_outputs or not rollout:
+        out = eng.alloc_outputs(T if rollout else None, matrix_codes=args.matrix_codes, slab=False)
+    else:
+        out = eng.alloc_outputs(T, matrix_codes=args.matrix_codes)          # engine-owned slab (tw_alloc_outputs)
+
+    def run(i_begin, n):
+        for i in range(i_begin, i_begin + n):
+            if rollout:
+                eng.rollout(T, out, actions=actions[i % n_act], autoreset=True, policy_idx=True)
+            else:
+                eng.step(actions[i, 0], out, autoreset=True, policy_idx=True)
+
+    run(0, W)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    sync_all(dev, world)
+    t0 = time.perf_counter()
+    e0.record()                     # torch's current stream == the stream handed to tw_rollout (engine._stream)
+    run(W, K)
+    e1.record()
+    sync_all(dev, world)
+    dt = time.perf_counter() - t0
+    ev_ms = e0.elapsed_time(e1)
+    dt = max_over_ranks(dt, dev, world)
+
+    bpe = algorithmic_bytes_per_env_step(V, T, 289 if args.matrix_codes else 289 * 4)
+    k_ms = ev_ms / K                                    # device time per launch, same K launches as `value`
+    bytes_per_launch = bpe * N * T
+    achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
+    traffic, traffic_src = (None, None) if args.matrix_codes or not rollout else traffic_from_profile(vname, N, T, V)
+    fill_gbs = fill_ceiling_gbs(dev)
+    if rank != 0:
+        return None
+    pipelined = rollout and os.environ.get("TW_PIPELINE", "1") != "0"
+    res = {
+        "metric": "env-steps/sec", "value": world * N * T * K / dt, "unit": "env-steps/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+        "data": "synthetic",
+        "config": {"workload": "MiniGrid-twoarmy-17x17-%s, %d envs/GPU, batched HIP step() only "
+                               "(BASELINE configs[1])%s" % (vname, N, " + uint8 code frames (configs[4] storage)"
+                                                               if args.matrix_codes else ""),
+                   "step": "one tw_rollout launch = %d env-steps x %d envs" % (T, N) if rollout
+                           else "one tw_step launch = 1 env-step x %d envs" % N,
+                   "env_steps_per_step": N * T, "envs_per_gpu": N, "view": V, "steps_per_launch": T, "autoreset": True,
+                   "actions": "Philox(seed=9981) policy indices 0..4 (4->done), resident in HBM",
+                   "outputs_per_step": "obs u8[N,V,V,3] + state_matrix %s[N,289] + pos f32[N,2] + reward f32 + term u8 + trunc u8"
+                                      % ("u8-code" if args.matrix_codes else "f32"),
+                   "parallelism": "env-sharded x%d, no data-path collective" % world,
+                   "collective": coll,
+                   "output_buffers": "torch caching allocator, two streams" if (args.torch_outputs or placement_ms or not rollout)
+                                     else "engine slab (tw_alloc_outputs): %s" % getattr(out["matrix"], "_tw_layout", "?"),
+                   "output_placement_probe_ms": placement_ms},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": "tw_pipe_kernel" if pipelined else "tw_rollout_kernel",
+                     "kernel_ms": k_ms, "launches_timed": K, "timed_region": "the same K launches as `value` "
+                     "(events on the launch stream)", "wall_over_event": dt * 1e3 / ev_ms,
+                     "algorithmic_bytes_per_env_step": bpe, "bytes_per_launch": bytes_per_launch,
+                     "survey_bytes_per_env_step": 2690, "us_per_env_batch_step": k_ms * 1e3 / T,
+                     "launches_per_env_batch_step": 1.0 / T, "measured_fill_ceiling_GBs": fill_gbs,
+                     "frac_of_measured_fill_ceiling": achieved / fill_gbs},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(variant, N, V)
+    eng.close()
+    return res
+
+
+def run_ppo_mode(args, rank, world, dev, coll):
+    """One step = one PPO iteration of this rank's envs: T-step rollout with the actor in the loop, then the update
+    (K epochs x minibatches, both networks, one gradient-bucket all-reduce per optimiser step when world > 1)."""
+    import torch
+    import torch.distributed as dist
+    from twoarmy_amd import dist as twdist
+    from twoarmy_amd.engine import TwoarmyEngine
+    from twoarmy_amd.soa.ppo_vec import VecPPOTrainer
+    vname = args.variant or "v4"
+    variant = {"v4": 4, "v6": 6}[vname]
+    N, T = args.envs, ROLLOUT_T
+    K = args.steps if args.steps is not None else 2
+    W = args.warmup if args.warmup is not None else 1
+    torch.manual_seed(SEED)
+    if args.predictor:
+        from twoarmy_amd.soa.agent.PPO_Predictor import ppo_predictor as Agent
+    else:
+        from twoarmy_amd.soa.agent.PPO import PPO as Agent
+    agent = Agent()
+    agent.K_epochs = args.k_epochs
+    agent.sample_seed = SEED + 7919 * rank
+    agent.amp_dtype = torch.bfloat16 if args.amp == "bf16" else None
+    agent.to(dev)
+    twdist.broadcast_parameters([agent.actor, agent.critic])
+    sync_ms = []
+    bucket = None
+    if world > 1:
+        bucket = twdist.GradBucket(list(agent.actor.parameters()) + list(agent.critic.parameters()))
+
+        def timed_sync(_params=None):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            bucket()
+            b.record()
+            sync_ms.append((a, b))
+        agent.grad_sync = timed_sync if dist.get_backend() == "nccl" else bucket
+    eng = TwoarmyEngine(variant, N, 17, device=dev, seed=SEED, env_id0=rank * N)
+    tr = VecPPOTrainer(agent, eng, rollout_steps=T, minibatch=args.minibatch, frame_codes=args.matrix_codes)
+    roll_s, upd_s, her_n = [], [], []
+
+    def iteration(timed):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tr.collect()
+        if args.her:
+            tr.relabel()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        h = 0 if tr.her is None else int(tr.her["t"].numel())
+        tr.update()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        tr.carry_over()
+        if timed:
+            roll_s.append(t1 - t0); upd_s.append(t2 - t1); her_n.append(h)
+
+    for _ in range(W):
+        iteration(False)
+    del sync_ms[:]
+    sync_all(dev, world)
+    t0 = time.perf_counter()
+    for _ in range(K):
+        iteration(True)
+    sync_all(dev, world)
+    dt = max_over_ranks(time.perf_counter() - t0, dev, world)
+    ar_ms = [a.elapsed_time(b) for a, b in sync_ms]
+    if rank != 0:
+        return None
+    S = N * T
+    samples = S + sum(her_n) / max(1, len(her_n))
+    opt_steps = args.k_epochs * -(-int(samples) // args.minibatch)
+    flop_upd = samples * FWD_FLOP_PER_SAMPLE_PER_NET * (2 + args.k_epochs * 3 * 2)
+    r, u = sum(roll_s) / K, sum(upd_s) / K
+    nparam = sum(p.numel() for p in list(agent.actor.parameters()) + list(agent.critic.parameters()) if p.requires_grad)
+    return {
+        "metric": "env-steps/sec", "value": world * S * K / dt, "unit": "env-steps/s", "n_gpus": world, "steps": K,
+        "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.amp == "fp32" else "bf16", "data": "synthetic",
+        "config": {"workload": "MiniGrid-twoarmy-17x17-%s, %d envs/GPU, full PPO%s (BASELINE configs[%s]): %d-step rollouts "
+                               "with the actor in the loop + update K=%d, minibatch %d"
+                               % (vname, N, " + predictor head" if args.predictor else "",
+                                  "4" if args.predictor else ("3" if world > 1 else "2"), T, args.k_epochs, args.minibatch),
+                   "step": "one PPO iteration = %d env-steps + %d optimiser steps" % (S, opt_steps),
+                   "envs_per_gpu": N, "rollout_s": r, "update_s": u, "rollout_env_steps_per_s_per_gpu": S / r,
+                   "her_records_per_iteration": sum(her_n) / max(1, len(her_n)),
+                   "parallelism": "env-sharded x%d, one gradient-bucket all-reduce per optimiser step" % world,
+                   "collective": coll,
+                   "grad_bucket": {"floats": nparam, "bytes": 4 * nparam, "allreduces_timed": len(ar_ms),
+                                   "ms_per_allreduce_mean": (sum(ar_ms) / len(ar_ms)) if ar_ms else None,
+                                   "ms_per_allreduce_min": min(ar_ms) if ar_ms else None,
+                                   "includes": "flatten + all_reduce + divide + scatter back (dist.GradBucket)"}},
+        "roofline": {"bound": "mfma", "achieved": flop_upd / u / 1e12, "peak": 157.3 if args.amp == "fp32" else 2500.0,
+                     "unit": "TFLOP/s", "frac": flop_upd / u / 1e12 / (157.3 if args.amp == "fp32" else 2500.0),
+                     "traffic": None, "what": "update phase: algorithmic conv/linear flops (47.5 MFLOP fwd per sample per "
+                     "net; targets 2 fwd + K x (fwd + 2x bwd) x 2 nets) / update wall time",
+                     "rollout_TFLOPs": S * FWD_FLOP_PER_SAMPLE_PER_NET / r / 1e12},
+    }
+
+
+def run_rehearsal(args, rank, world, dev, coll):
+    """Launcher and process-group plumbing without the engine (CPU-only hosts): W + K empty steps."""
+    K = args.steps if args.steps is not None else 2
+    W = args.warmup if args.warmup is not None else 1
+    sync_all(None, world)
+    t0 = time.perf_counter()
+    for _ in range(K):
+        pass
+    sync_all(None, world)
+    dt = max_over_ranks(time.perf_counter() - t0, None, world)
+    if rank != 0:
+        return None
+    return {"metric": "env-steps/sec", "value": 0.0, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "data": "rehearsal", "config": {"workload": "launcher rehearsal: no engine, nothing measured",
+                                            "collective": coll}}
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = build_parser().parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, argv)             # parent: nothing below runs here
+    import torch.distributed as dist
+    rank, world, dev, coll = init_ranks(args)
+    if args.rehearse:
+        res = run_rehearsal(args, rank, world, dev, coll)
+    elif args.mode == "ppo":
+        res = run_ppo_mode(args, rank, world, dev, coll)
+    else:
+        res = run_engine_mode(args, rank, world, dev, coll)
     if rank == 0:
-        res = {
-            "metric": "env-steps/sec", "value": world * N * K / dt, "unit": "env-steps/s",
-            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
-            "data": "synthetic",
-            "config": {"workload": "MiniGrid-twoarmy-17x17-%s, %d envs/GPU, batched HIP step() only "
-                                   "(BASELINE configs[1])%s" % (args.variant, N, " + uint8 code frames (configs[4] storage)"
-                                                                   if args.matrix_codes else ""),
-                       "envs_per_gpu": N, "view": V, "steps_per_launch": T, "autoreset": True,
-                       "actions": "Philox(seed=9981) policy indices 0..4 (4->done), resident in HBM",
-                       "outputs_per_step": "obs u8[N,V,V,3] + state_matrix %s[N,289] + pos f32[N,2] + reward f32 + term u8 + trunc u8"
-                                          % ("u8-code" if args.matrix_codes else "f32"),
-                       "parallelism": "env-sharded x%d, no collective" % world,
-                       "output_placement": None if placement_ms is None else {
-                           "what": "untimed set-up: %d output buffer sets allocated, the fastest kept (HBM placement of the "
-                                   "two output streams moves the store bandwidth by up to 25 %%)" % len(placement_ms),
-                           "probe_kernel_ms": placement_ms}},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)"
-                                           if traffic is not None else None,
-                         "kernel": "tw_pipe_kernel (+ flag-gated tw_rollout_kernel fallback launch)" if T >= 8 and os.environ.get("TW_PIPELINE", "1") != "0" else "tw_rollout_kernel", "kernel_ms": k_ms, "launches_timed": iters,
-                         "algorithmic_bytes_per_env_step": bpe, "bytes_per_launch": bytes_per_launch,
-                         "survey_bytes_per_env_step": 2690, "us_per_env_batch_step": k_ms * 1e3 / T,
-                         "launches_per_env_batch_step": 2.0 / T, "measured_fill_ceiling_GBs": fill_gbs,
-                         "frac_of_measured_fill_ceiling": achieved / fill_gbs},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(variant, N, V)
         print(json.dumps(res), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -39,6 +39,15 @@ def build(force=False):
 
 
 _vp = C.c_void_p
+
+
+class TwOutputs(C.Structure):
+    """struct tw_outputs (include/twoarmy.h)."""
+    _fields_ = [("obs", _vp), ("matrix", _vp), ("pos", _vp), ("reward", _vp), ("terminated", _vp), ("truncated", _vp),
+                ("obs_pitch", C.c_int), ("mat_pitch", C.c_int), ("T", C.c_int), ("n_envs", C.c_int), ("flags", C.c_int),
+                ("device", C.c_int), ("backing", C.c_int), ("slab_bytes", C.c_uint64), ("slab", _vp)]
+
+
 _SIGS = {
     "tw_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32]),
     "tw_destroy": (C.c_int, [_vp]),
@@ -58,6 +67,8 @@ _SIGS = {
     "tw_last_hip_error": (C.c_int, []),
     "tw_version": (C.c_char_p, []),
     "tw_last_error_message": (C.c_char_p, []),
+    "tw_alloc_outputs": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(TwOutputs)]),
+    "tw_free_outputs": (C.c_int, [C.POINTER(TwOutputs)]),
     "tw_time_rollout": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp,
                                   C.POINTER(C.c_float)]),
 }

@@ -32,7 +32,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <map>
+#include <mutex>
 #include <type_traits>
+#include <vector>
 
 #include "twoarmy.h"
 
@@ -67,6 +71,9 @@ constexpr int MATC_OFF = MAT_OFF + MAT_WORDS;    // 1448: byte image of the matr
 constexpr int MATC_BYTES = 304;                 // 289 + pad to 16
 constexpr int ENV_WORDS = MATC_OFF + MATC_BYTES / 4;   // 1524
 constexpr int STAGE_WORDS = 220;
+// record layout of the outputs (tw_alloc_outputs): one 2048-byte block per env-step, 292 floats of matrix then 880 bytes of image
+constexpr int REC_BYTES = 2048, REC_OBS_OFF = MAT_WORDS * 4;
+static_assert(REC_OBS_OFF + 880 == REC_BYTES, "matrix row + view-17 image row fill the record exactly");
 
 enum { R_STEP = 0, R_RISK = 1, R_HIT = 2, R_ROOM2 = 3, R_GOAL = 4 };
 
@@ -97,6 +104,7 @@ struct Params {
     int obs_pitch;            // bytes between consecutive envs' images
     int mat_pitch;            // floats between consecutive envs' matrices
     int flags;
+    int record;               // record layout: one 2048-byte block per env-step = 1168 B matrix row | 880 B image row
 };
 
 // ---------------------------------------------------------------- Philox4x32-10
@@ -320,13 +328,17 @@ struct ObsFast {
     uint32_t shift;
     uint32_t andm[4], orm[4];
     int active;
+    int chunk;                // 16-byte chunk of the image this lane produces (== lane, or lane - 9 in the record layout)
 };
 
-__device__ __forceinline__ ObsFast make_obs_fast(int lane, int V) {
+// chunk = index of the 16-byte piece of the image the calling lane owns (negative or past the image: idle lane)
+__device__ __forceinline__ ObsFast make_obs_fast(int chunk, int V) {
     ObsFast f;
     const int VV = V * V, h = V >> 1, nb = VV * 3;
     const int nchunks = (nb + 15) >> 4;
-    f.active = lane < nchunks;
+    f.active = chunk >= 0 && chunk < nchunks;
+    f.chunk = f.active ? chunk : 0;
+    const int lane = f.chunk;
     const int s0 = 16 * lane;
     const int c0 = s0 / 3;
     f.shift = 8u * (uint32_t)(s0 - 3 * c0);
@@ -371,7 +383,7 @@ __device__ __forceinline__ void emit_obs_fast(const uint32_t *env, int ax, int a
     o.y = (__builtin_amdgcn_alignbit(w2, w1, f.shift) & f.andm[1]) | f.orm[1];
     o.z = (__builtin_amdgcn_alignbit(w3, w2, f.shift) & f.andm[2]) | f.orm[2];
     o.w = (__builtin_amdgcn_alignbit(w4, w3, f.shift) & f.andm[3]) | f.orm[3];
-    *reinterpret_cast<uint4 *>(dst + 16 * lane) = o;
+    *reinterpret_cast<uint4 *>(dst + 16 * f.chunk) = o;
 }
 
 // ---------------------------------------------------------------- state matrix (env_buffer.py:300-318)
@@ -1111,8 +1123,11 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
     }
     __syncthreads();
 
-    // ---- emission constants of this lane
-    const ObsFast of = make_obs_fast(lane, V);
+    // ---- emission constants of this lane.  Record layout (tw_alloc_outputs): the env-step's 2048-byte block is
+    // written by exactly two full-wave stores of eight whole 128-byte lines each -- lanes 0..63 matrix floats 0..255,
+    // then lanes 0..8 matrix floats 256..291 and lanes 9..63 the 55 image chunks.
+    const bool record = p.record != 0;
+    const ObsFast of = make_obs_fast(record ? lane - 9 : lane, V);
     // dynamic-cell slot of this lane: 0-2 balls, 3-10 wall blocks, 11-13 patrol column, 14-17 patrol square
     // Every lane decodes the packed record for itself with per-lane shift/mask constants (the scalar unit is
     // shared by the CU's four SIMDs and was the emission waves' bottleneck):
@@ -1381,13 +1396,22 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
                     o.y = (__builtin_amdgcn_alignbit(w2, w1, of.shift) & of.andm[1]) | of.orm[1];
                     o.z = (__builtin_amdgcn_alignbit(w3, w2, of.shift) & of.andm[2]) | of.orm[2];
                     o.w = (__builtin_amdgcn_alignbit(w4, w3, of.shift) & of.andm[3]) | of.orm[3];
-                    if (of.active) store16(obs_dst + 16 * lane, o);
-                    if (!code_mode) {
+                    if (record) {
+                        uint8_t *rec_dst = reinterpret_cast<uint8_t *>(mat_dst);
+                        store16(rec_dst + 16 * lane, m0);
+                        uint4 b;
+                        b.x = lane < 9 ? m1.x : o.x; b.y = lane < 9 ? m1.y : o.y;
+                        b.z = lane < 9 ? m1.z : o.z; b.w = lane < 9 ? m1.w : o.w;
+                        if ((lane < 9) | of.active) store16(rec_dst + 1024 + 16 * lane, b);
+                    } else if (!code_mode) {
+                        if (of.active) store16(obs_dst + 16 * lane, o);
                         store16(mat_dst + 4 * lane, m0);
                         if (lane < 9) store16(mat_dst + 4 * (64 + lane), m1);
-                    } else if (lane < MATC_BYTES / 16) {
-                        *reinterpret_cast<uint4 *>(matc_dst + 16 * lane) =
-                            *reinterpret_cast<const uint4 *>(img_bytes + MATC_OFF * 4 + 16 * lane);
+                    } else {
+                        if (of.active) store16(obs_dst + 16 * lane, o);
+                        if (lane < MATC_BYTES / 16)
+                            *reinterpret_cast<uint4 *>(matc_dst + 16 * lane) =
+                                *reinterpret_cast<const uint4 *>(img_bytes + MATC_OFF * 4 + 16 * lane);
                     }
                     wave_sync();
                     my_img[gidx] = C_EMPTY;                               // un-patch (trash words may hold anything)
@@ -1542,6 +1566,7 @@ struct tw_engine {
     int parity;
     int envs_per_wave;              // 0 = auto
     int pipeline;                   // 1 = use the pipelined kernel when eligible (TW_PIPELINE=0 disables)
+    int slab_backing;               // how tw_alloc_outputs backs its slab (0 hipMalloc, 1 mapped 2 MiB granules, ...)
 };
 
 namespace {
@@ -1635,6 +1660,8 @@ int launch_rollout(tw_engine *e, int T, const int32_t *actions, const uint32_t *
     if (obs_pitch > 0) p.obs_pitch = obs_pitch;
     if (mat_pitch > 0) p.mat_pitch = mat_pitch;
     if (p.obs_pitch < e->view * e->view * 3 || p.mat_pitch < NC) return TW_E_ARG;   // pitch: floats, or bytes with TW_F_MATRIX_CODE
+    p.record = !(flags & TW_F_MATRIX_CODE) && obs && matrix && p.obs_pitch == REC_BYTES && p.mat_pitch == REC_BYTES / 4 &&
+               obs == reinterpret_cast<uint8_t *>(matrix) + REC_OBS_OFF && ((uintptr_t)matrix & 127u) == 0;
     const bool pipe = e->pipeline && T >= PIPE_MIN_T && (flags & TW_F_AUTORESET) && params_fast(e, p, true);
     if (!pipe) return launch_sequential(e, p, st);
     // pipelined launch: cur -> next, with the sequential kernel as a flag-gated fallback from the same input
@@ -1684,6 +1711,7 @@ int tw_create(tw_engine **out, int variant, int n_envs, int view_size, int devic
     e->envs_per_wave = epw ? atoi(epw) : 0;
     const char *pl = getenv("TW_PIPELINE");
     e->pipeline = pl ? atoi(pl) : 1;
+    e->slab_backing = 1;            // 2 MiB chunks created one by one, mapped in creation order (see slab_alloc)
     hipError_t rr[7];
     rr[0] = hipMalloc((void **)&e->type, (size_t)n_envs * NC);
     rr[1] = hipMalloc((void **)&e->colour, (size_t)n_envs * NC);
@@ -1835,6 +1863,155 @@ int tw_debug_stamps(unsigned long long *out512) {
 }
 #endif
 
+// ---------------------------------------------------------------- engine-owned output slab
+namespace {
+
+struct Slab {
+    void *base = nullptr;
+    size_t bytes = 0;
+    int backing = 0;                                  // 0 hipMalloc, >0 mapped hipMemCreate granules
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+};
+std::mutex g_slab_mu;
+std::map<void *, Slab> g_slabs;
+
+void slab_release(Slab &s) {
+    if (!s.base) return;
+    if (s.backing == 0) { (void)hipFree(s.base); }
+    else {
+        (void)hipMemUnmap(s.base, s.bytes);
+        for (auto h : s.handles) (void)hipMemRelease(h);
+        (void)hipMemAddressFree(s.base, s.bytes);
+    }
+    s.base = nullptr;
+}
+
+// backing: 0 hipMalloc; k > 0: the slab is a contiguous virtual range backed by separately created physical chunks
+// (hipMemCreate) of 2^(k-1) x 2 MiB each: 1 -> 2 MiB, 2 -> 4 MiB, 5 -> 32 MiB, ...; 99 -> one chunk for the slab.
+// Default 1.  Measured (tools/placement_probe2.py, 4096 x 128 record-layout rollout, 4 slabs each, ms per launch):
+// hipMalloc / one chunk / 32-256 MiB chunks 0.190-0.197; 2 MiB chunks mapped in creation order 0.178-0.189; the same
+// chunks mapped in reverse order 0.192-0.196 (= the contiguous case: the driver hands out physical memory top-down,
+// so reverse order IS physically ascending); shuffled 0.199-0.201.  Why a stream whose 2 MiB pages descend
+// physically absorbs these stores ~5 % faster than an ascending one is not understood; it is kept because it is
+// reproducible on every box tried and the fallback (hipMalloc) is what every other allocation gets anyway.
+// Diagnostic knob TW_SLAB_ORDER: 0 map the chunks in creation order, 1 in reverse order, 2 shuffled.
+int slab_alloc(int device, size_t bytes, int backing, Slab &s) {
+    s.bytes = bytes; s.backing = backing; s.base = nullptr;
+    if (backing == 0) {
+        HIP_TRY(hipMalloc(&s.base, bytes));
+        return TW_OK;
+    }
+    hipMemAllocationProp prop;
+    memset(&prop, 0, sizeof(prop));
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    size_t gran = 0;
+    HIP_TRY(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+    if (gran < ((size_t)2 << 20)) gran = (size_t)2 << 20;
+    size_t chunk = backing >= 99 ? bytes : ((size_t)2 << 20) << (backing - 1);
+    chunk = (chunk + gran - 1) / gran * gran;
+    s.bytes = (bytes + chunk - 1) / chunk * chunk;
+    const size_t nchunks = s.bytes / chunk;
+    hipError_t err = hipMemAddressReserve(&s.base, s.bytes, gran, nullptr, 0);
+    if (err != hipSuccess) { s.base = nullptr; return hip_fail(err); }
+    const char *ord_s = getenv("TW_SLAB_ORDER");
+    const int order = ord_s ? atoi(ord_s) : 0;
+    std::vector<size_t> slot(nchunks);
+    for (size_t i = 0; i < nchunks; ++i) slot[i] = order == 1 ? nchunks - 1 - i : i;
+    if (order == 2) {
+        uint64_t r = 0x9E3779B97F4A7C15ull;
+        for (size_t i = nchunks; i > 1; --i) {
+            r = r * 6364136223846793005ull + 1442695040888963407ull;
+            std::swap(slot[i - 1], slot[(size_t)((r >> 33) % i)]);
+        }
+    }
+    std::vector<char> is_mapped(nchunks, 0);
+    for (size_t i = 0; i < nchunks; ++i) {
+        hipMemGenericAllocationHandle_t h;
+        err = hipMemCreate(&h, chunk, &prop, 0);
+        if (err != hipSuccess) break;
+        err = hipMemMap((char *)s.base + slot[i] * chunk, chunk, 0, h, 0);
+        if (err != hipSuccess) { (void)hipMemRelease(h); break; }
+        s.handles.push_back(h);
+        is_mapped[slot[i]] = 1;
+    }
+    if (err == hipSuccess) {
+        hipMemAccessDesc acc;
+        memset(&acc, 0, sizeof(acc));
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        err = hipMemSetAccess(s.base, s.bytes, &acc, 1);
+    }
+    if (err != hipSuccess) {
+        for (size_t i = 0; i < nchunks; ++i)
+            if (is_mapped[i]) (void)hipMemUnmap((char *)s.base + i * chunk, chunk);
+        for (auto h : s.handles) (void)hipMemRelease(h);
+        s.handles.clear();
+        (void)hipMemAddressFree(s.base, s.bytes);
+        s.base = nullptr;
+        return hip_fail(err);
+    }
+    return TW_OK;
+}
+
+size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+int tw_alloc_outputs(tw_engine *e, int T, int flags, tw_outputs *out) {
+    if (!e || !out || T <= 0) return TW_E_ARG;
+    DeviceGuard g(e->device);
+    memset(out, 0, sizeof(*out));
+    const size_t TN = (size_t)T * e->n_envs;
+    const bool codes = (flags & TW_F_MATRIX_CODE) != 0;
+    const int obs_row = ((e->view * e->view * 3 + 15) >> 4) << 4;
+    // float frames: ONE stream of 2048-byte records (matrix row | image row) -- two separate streams made the store
+    // bandwidth depend on where the driver happened to place them (0.178 ... 0.220 ms per launch);
+    // code frames (304-byte rows) keep two streams
+    const bool rec = !codes;
+    const size_t mat_row = codes ? (size_t)MATC_BYTES : (size_t)MAT_WORDS * 4;
+    const size_t A = (size_t)2 << 20;                 // every stream starts on a 2 MiB page
+    const size_t sz[6] = {rec ? TN * (size_t)REC_BYTES : TN * mat_row, rec ? 0 : TN * (size_t)obs_row, TN * 8, TN * 4, TN, TN};
+    size_t off[6], total = 0;
+    const char *gap_s = getenv("TW_SLAB_GAP_KB");          // diagnostic: extra gap between the matrix and the obs stream
+    const size_t gap = gap_s ? (size_t)atol(gap_s) << 10 : 0;
+    for (int i = 0; i < 6; ++i) { off[i] = total + (i >= 1 ? gap : 0); total = off[i] + round_up(sz[i], A); }
+    // backing: mapped 2 MiB granules by default (TW_SLAB_BACKING=0..3 overrides); hipMalloc when the runtime refuses
+    const char *bk = getenv("TW_SLAB_BACKING");
+    int backing = bk ? atoi(bk) : e->slab_backing;
+    Slab s;
+    int rc = slab_alloc(e->device, total, backing, s);
+    if (rc != TW_OK && backing != 0) { backing = 0; rc = slab_alloc(e->device, total, 0, s); }
+    if (rc != TW_OK) return rc;
+    char *b = (char *)s.base;
+    out->matrix = b + off[0]; out->obs = (uint8_t *)(rec ? b + off[0] + REC_OBS_OFF : b + off[1]); out->pos = (float *)(b + off[2]);
+    out->reward = (float *)(b + off[3]); out->terminated = (uint8_t *)(b + off[4]); out->truncated = (uint8_t *)(b + off[5]);
+    out->obs_pitch = rec ? REC_BYTES : obs_row; out->mat_pitch = codes ? MATC_BYTES : (rec ? REC_BYTES / 4 : MAT_WORDS);
+    out->T = T; out->n_envs = e->n_envs; out->flags = flags & TW_F_MATRIX_CODE; out->device = e->device;
+    out->backing = s.backing; out->slab_bytes = s.bytes; out->slab = s.base;
+    std::lock_guard<std::mutex> lk(g_slab_mu);
+    g_slabs[s.base] = s;
+    return TW_OK;
+}
+
+int tw_free_outputs(tw_outputs *out) {
+    if (!out || !out->slab) return TW_E_ARG;
+    DeviceGuard g(out->device);
+    Slab s;
+    {
+        std::lock_guard<std::mutex> lk(g_slab_mu);
+        auto it = g_slabs.find(out->slab);
+        if (it == g_slabs.end()) return TW_E_ARG;
+        s = it->second;
+        g_slabs.erase(it);
+    }
+    (void)hipDeviceSynchronize();
+    slab_release(s);
+    memset(out, 0, sizeof(*out));
+    return TW_OK;
+}
+
 int tw_n_envs(const tw_engine *e) { return e ? e->n_envs : TW_E_ARG; }
 int tw_view_size(const tw_engine *e) { return e ? e->view : TW_E_ARG; }
 int tw_last_hip_error(void) { return g_last_hip_error; }
@@ -1847,20 +2024,22 @@ int tw_time_rollout(tw_engine *e, int T, const int32_t *actions, uint8_t *obs, i
     if (!e || T <= 0 || iters <= 0 || !ms_per_launch) return TW_E_ARG;
     DeviceGuard g(e->device);
     hipStream_t st = (hipStream_t)stream;
-    hipEvent_t a, b;
+    hipEvent_t a = nullptr, b = nullptr;
     HIP_TRY(hipEventCreate(&a));
-    HIP_TRY(hipEventCreate(&b));
-    HIP_TRY(hipEventRecord(a, st));
-    for (int i = 0; i < iters; ++i) {
-        int rc = launch_rollout(e, T, actions, nullptr, obs, obs_pitch, state_matrix, mat_pitch, pos, reward,
-                                terminated, truncated, flags, st);
-        if (rc != TW_OK) return rc;
-    }
-    HIP_TRY(hipEventRecord(b, st));
-    HIP_TRY(hipEventSynchronize(b));
+    hipError_t he = hipEventCreate(&b);
+    int rc = TW_OK;
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, a, b));
-    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    if (he == hipSuccess) he = hipEventRecord(a, st);
+    for (int i = 0; he == hipSuccess && rc == TW_OK && i < iters; ++i)
+        rc = launch_rollout(e, T, actions, nullptr, obs, obs_pitch, state_matrix, mat_pitch, pos, reward,
+                            terminated, truncated, flags, st);
+    if (he == hipSuccess && rc == TW_OK) he = hipEventRecord(b, st);
+    if (he == hipSuccess && rc == TW_OK) he = hipEventSynchronize(b);
+    if (he == hipSuccess && rc == TW_OK) he = hipEventElapsedTime(&ms, a, b);
+    (void)hipEventDestroy(a);                         // both events are released on every path
+    if (b) (void)hipEventDestroy(b);
+    if (rc != TW_OK) return rc;
+    if (he != hipSuccess) return hip_fail(he);
     *ms_per_launch = ms / (float)iters;
     return TW_OK;
 }

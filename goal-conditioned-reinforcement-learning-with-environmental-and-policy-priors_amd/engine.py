@@ -12,6 +12,7 @@ from ._lib import FIELDS, TW_CELLS, TW_DRAW_WORDS, TW_F_AUTORESET, TW_F_MATRIX_C
 
 REWARD_VALUES = (-0.01, -0.1, -0.9, 0.2, 0.9)
 MAT_PITCH = 292                       # floats per env matrix in the native layout (289 + 3 zero pad)
+REC_BYTES = 2048                      # record layout of tw_alloc_outputs: 292 floats of matrix | 880 bytes of image per env-step
 MATC_PITCH = 304                      # bytes per env matrix in the code layout (TW_F_MATRIX_CODE; 289 + 15 pad)
 MATRIX_CODE_VALUES = (0.9, -0.9, -0.5, 0.3)     # code -> Env_transact.matrix_env value (free/goal, wall, ball, agent)
 
@@ -62,6 +63,47 @@ def _pitched(t, lead, inner_shape, dtype):
     return C.c_void_p(t.data_ptr()), int(pitch)
 
 
+def padded_rows(t, nlead, width):
+    """The padded rows behind a native-layout output: [*lead, width] view of every row including its pad bytes /
+    floats (t is the [*lead, ...] strided view handed out by alloc_outputs; nlead = len(lead); width = 880 / 292 / 304)."""
+    lead = tuple(t.shape[:nlead])
+    assert width <= t.stride(nlead - 1)
+    strides = tuple(t.stride(d) for d in range(nlead)) + (1,)
+    return t.as_strided(lead + (width,), strides)
+
+
+class _DevSpan:
+    """A span of a library-owned device slab, exported through __cuda_array_interface__ so that torch wraps it without
+    copying; torch keeps this object (and through it the slab) alive as long as any view of the tensor lives."""
+
+    def __init__(self, owner, ptr, nbytes):
+        self.owner = owner
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+class _OutputSlab:
+    """One tw_alloc_outputs slab; freed (tw_free_outputs) when the last tensor carved from it is gone."""
+
+    def __init__(self, engine, T, flags):
+        self.out = _lib.TwOutputs()
+        self.device = engine.device
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().tw_alloc_outputs(engine._h, int(T), int(flags), C.byref(self.out)), "tw_alloc_outputs")
+        self.backing = int(self.out.backing)
+
+    def tensor(self, ptr, nbytes, dtype):
+        t = torch.as_tensor(_DevSpan(self, ptr, nbytes), device=self.device)
+        return t.view(dtype)
+
+    def __del__(self):
+        try:
+            if self.out.slab:
+                _lib.lib().tw_free_outputs(C.byref(self.out))
+        except Exception:
+            pass
+
+
 class TwoarmyEngine:
     """N independent MiniGrid-Twoarmy envs living in HBM on one GPU.
 
@@ -69,7 +111,7 @@ class TwoarmyEngine:
     (reference gym_minigrid/__init__.py:6-21).
     """
 
-    def __init__(self, variant, num_envs, view_size=17, device=None, seed=9981, env_id0=0):
+    def __init__(self, variant, num_envs, view_size=17, device=None, seed=9981, env_id0=0, max_steps=50):
         variant = {"v4": 4, "v6": 6}.get(variant, variant)
         if not torch.cuda.is_available():
             raise _lib.TwoarmyLibraryError("TwoarmyEngine needs a GPU (no CPU fallback)")
@@ -82,6 +124,13 @@ class TwoarmyEngine:
             torch.cuda.current_stream().synchronize()
             _lib.check(lib.tw_create(C.byref(self._h), variant, self.num_envs, self.view_size,
                                      self.device.index or 0, self.seed, self.env_id0), "tw_create")
+        self.max_steps = int(max_steps)
+        if self.max_steps != 50:              # MiniGridEnv(max_steps=...) (minigrid.py:866-945; Twoarmy passes 50)
+            if self.max_steps <= 0:
+                raise ValueError("max_steps must be positive")
+            _, _, rec = self.get_state()
+            rec[:, FIELDS["MAX_STEPS"]] = self.max_steps
+            self.set_state(records=rec)
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
@@ -105,17 +154,25 @@ class TwoarmyEngine:
         _lib.check(_lib.lib().tw_set_envs_per_wave(self._h, int(e)), "tw_set_envs_per_wave")
 
     # ------------------------------------------------------------------ buffers
-    def alloc_outputs(self, T=None, obs=True, matrix=True, dense=False, matrix_codes=False):
+    def alloc_outputs(self, T=None, obs=True, matrix=True, dense=False, matrix_codes=False, slab=None):
         """Output tensors for step (T=None -> [N,...]) or rollout ([T,N,...]).
 
         Native layout (dense=False): obs rows padded to 16 bytes (880 for V=17) and matrix rows to
         292 floats; the returned tensors are [..., V, V, 3] / [..., 289] strided views of them.
         matrix_codes=True: the matrix is uint8 codes (rows of 304 bytes natively), see TW_F_MATRIX_CODE;
-        a uint8 matrix tensor selects that mode in step/rollout."""
+        a uint8 matrix tensor selects that mode in step/rollout.
+        slab (default: on for the native layout with every output): the buffers are carved out of ONE slab the
+        library allocates (tw_alloc_outputs) -- the same placement for every user of the C ABI; the tensors keep the
+        slab alive.  slab=False takes them from torch's caching allocator."""
         N, V = self.num_envs, self.view_size
         lead = (N,) if T is None else (T, N)
         d = self.device
         nb = V * V * 3
+        if slab is None:
+            slab = (not dense) and obs and matrix
+        if slab:
+            assert not dense and obs and matrix, "the engine slab holds the native layout with every output"
+            return self._slab_outputs(T, lead, matrix_codes)
         if dense:
             o = torch.empty(lead + (V, V, 3), dtype=torch.uint8, device=d) if obs else None
             m = torch.empty(lead + (TW_CELLS,), dtype=torch.uint8 if matrix_codes else torch.float32, device=d) \
@@ -137,6 +194,29 @@ class TwoarmyEngine:
             truncated=torch.empty(lead, dtype=torch.uint8, device=d),
         )
 
+    def _slab_outputs(self, T, lead, matrix_codes):
+        N, V = self.num_envs, self.view_size
+        owner = _OutputSlab(self, 1 if T is None else T, TW_F_MATRIX_CODE if matrix_codes else 0)
+        o = owner.out
+        TN = (1 if T is None else T) * N
+        nb = V * V * 3
+        if matrix_codes:
+            obs = owner.tensor(o.obs, TN * o.obs_pitch, torch.uint8).view(lead + (o.obs_pitch,))[..., :nb].view(lead + (V, V, 3))
+            m = owner.tensor(o.matrix, TN * o.mat_pitch, torch.uint8).view(lead + (o.mat_pitch,))[..., :TW_CELLS]
+        else:
+            # record layout: [*lead] blocks of REC_BYTES = 292 floats of matrix | 880 bytes of image (include/twoarmy.h)
+            assert o.obs_pitch == REC_BYTES and o.mat_pitch * 4 == REC_BYTES and o.obs == o.matrix + MAT_PITCH * 4
+            rec = owner.tensor(o.matrix, TN * REC_BYTES, torch.uint8).view(lead + (REC_BYTES,))
+            m = rec[..., :MAT_PITCH * 4].view(torch.float32)[..., :TW_CELLS]
+            obs = rec[..., MAT_PITCH * 4:MAT_PITCH * 4 + nb].view(lead + (V, V, 3))
+        m._tw_layout = ("code frames, two streams" if matrix_codes else "2048-byte records (matrix | image)") + \
+            (", hipMalloc" if o.backing == 0 else ", 2 MiB mapped chunks")
+        return dict(obs=obs, matrix=m,
+                    pos=owner.tensor(o.pos, TN * 8, torch.float32).view(lead + (2,)),
+                    reward=owner.tensor(o.reward, TN * 4, torch.float32).view(lead),
+                    terminated=owner.tensor(o.terminated, TN, torch.uint8).view(lead),
+                    truncated=owner.tensor(o.truncated, TN, torch.uint8).view(lead))
+
     def alloc_outputs_tuned(self, T, candidates=6, iters=4, **kw):
         """alloc_outputs(T) with an HBM placement probe: `candidates` output sets are allocated side by side, a few
         rollouts are timed into each (HIP events), the fastest set is kept and the others are released.
@@ -147,7 +227,7 @@ class TwoarmyEngine:
         tools/placement_probe.py).  The env state is restored after probing.  Returns (outputs, probe_ms list)."""
         state = self.get_state()
         acts = self.fill_actions(T)
-        sets = [self.alloc_outputs(T, **kw) for _ in range(int(candidates))]
+        sets = [self.alloc_outputs(T, slab=False, **kw) for _ in range(int(candidates))]
         ms = [self.time_rollout(T, o, actions=acts, iters=iters) for o in sets]
         ms = [min(a, self.time_rollout(T, o, actions=acts, iters=iters)) for a, o in zip(ms, sets)]     # second pass: warm clocks
         best = min(range(len(sets)), key=lambda k: ms[k])

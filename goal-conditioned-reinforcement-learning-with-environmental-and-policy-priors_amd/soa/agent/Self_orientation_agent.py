@@ -155,6 +155,19 @@ class self_orinetation_agent(ppo_predictor):
         self.update_count_fp += 1
         return loss.detach()
 
+    def orientation_idle_step(self):
+        """Optimiser step of a rank that has no orientation sample this update: zero local gradients, the same
+        all-reduce and Adam step as its peers, so replicas stay identical and no collective is skipped."""
+        self.optimizer_agent_position_preditor.zero_grad()
+        for p in self.agent_position_preditor.parameters():
+            p.grad = torch.zeros_like(p)
+        if self.grad_sync_orient is not None:
+            self.grad_sync_orient(list(self.agent_position_preditor.parameters()))
+        if self.use_grad_clip:
+            torch.nn.utils.clip_grad_norm_(self.agent_position_preditor.parameters(), 0.5)
+        self.optimizer_agent_position_preditor.step()
+        self.update_count_fp += 1
+
     def update_orientation(self, buffer, device, i_ep, permutations=None):
         """Reference signature (:242-294): the target is the position three states after the acting one minus the
         acting one, p[:, 6] - p[:, 3], which the window construction keeps within -3..3."""

@@ -6,9 +6,13 @@ stack per record, train_ppo.py:93-97): frames[k] for k = -3..T, pos[k], age[t] (
 reset).  The 4-frame policy input of any (t, n) is assembled on the fly by ppo_gather_stack, which
 repeats the reset frame at episode starts exactly like np.tile in Env_transact.reset.
 """
+import collections
+
 import torch
 
 from .. import ppo_ops
+
+HER_MAX_LEN = 64              # longest episode ppo_her_relabel handles (csrc/ppo_kernels.hip)
 
 INIT_POS = (15.0, 3.0)        # agent (y, x) after reset (twoarmy_v6.py:10, env_buffer.py:320-322)
 GOAL_YX = (2.0, 14.0)
@@ -47,7 +51,10 @@ class VecPPOTrainer:
         self.pos[:4] = self.init_pos
         agent.to(d)
         self.her = None                       # relabelled index records of the current rollout (relabel())
-        self._prev = None                     # (pos, term, trunc, reward, age0) of the previous rollout
+        # hindsight relabelling looks back over every rollout an episode ending now may have started in:
+        # ceil((max_steps - 1) / T) earlier ones; each entry is (pos, term, trunc, reward, age0) of one rollout
+        self.max_steps = int(getattr(engine, "max_steps", 50))
+        self._hist = collections.deque(maxlen=max(1, -(-(self.max_steps - 1) // self.T)))
         self.her_seed = int(getattr(engine, "seed", 9981))
         self.env_steps = 0
         self.episodes_done = 0
@@ -90,8 +97,8 @@ class VecPPOTrainer:
         """Make the last 4 frames the history of the next rollout (and keep what hindsight relabelling needs of
         this one: episodes that end in the next rollout start here)."""
         T = self.T
-        self._prev = (self.pos[4:4 + T].clone(), self.term.clone(), self.trunc.clone(), self.reward.clone(),
-                      self.age[0].clone())
+        self._hist.append((self.pos[4:4 + T].clone(), self.term.clone(), self.trunc.clone(), self.reward.clone(),
+                           self.age[0].clone()))
         self.frames_buf[:4] = self.frames_buf[T:T + 4].clone()
         self.pos[:4] = self.pos[T:T + 4].clone()
         self.age[0] = self.age[T]
@@ -112,22 +119,29 @@ class VecPPOTrainer:
         (ppo_her_relabel); update() then trains on the rollout plus these records, like the reference trains on
         its ring buffer with the appended copies.
 
-        Episodes that began in the previous rollout are relabelled over the two-rollout window (positions, rewards and
-        done flags of the previous rollout are kept by carry_over); only their records that lie in the current rollout
-        are returned -- the earlier part of such a prefix belongs to samples whose frames are gone."""
+        Episodes that began in an earlier rollout are relabelled over a window of rollouts long enough to hold any
+        episode that ends now (carry_over keeps positions, rewards and done flags of ceil((max_steps-1)/T) earlier
+        rollouts); only the records that lie in the current rollout are returned -- the earlier part of such a prefix
+        belongs to samples whose frames are gone."""
         T, N = self.T, self.N
+        if self.max_steps > HER_MAX_LEN:
+            raise ValueError("hindsight relabelling handles episodes of up to %d steps (max_steps = %d)"
+                             % (HER_MAX_LEN, self.max_steps))
         start = self.env_steps // N - T                       # global step index of this rollout's first step
-        if self._prev is None or choices is not None:
+        if not self._hist or choices is not None:
             self.her = ppo_ops.her_relabel(self.pos[4:4 + T], self.term, self.trunc, self.age[0].contiguous(),
                                            self.reward, choices, seed=self.her_seed, env_id0=self.engine.env_id0,
                                            step0=start, max_goals=max_goals)
             return self.her
-        ppos, pterm, ptrunc, prew, page0 = self._prev
-        h = ppo_ops.her_relabel(torch.cat([ppos, self.pos[4:4 + T]]), torch.cat([pterm, self.term]),
-                                torch.cat([ptrunc, self.trunc]), page0, torch.cat([prew, self.reward]), None,
-                                seed=self.her_seed, env_id0=self.engine.env_id0, step0=start - T, max_goals=max_goals)
-        keep = h["t"] >= T
-        self.her = dict(t=(h["t"][keep] - T).contiguous(), n=h["n"][keep].contiguous(), goal=h["goal"][keep].contiguous(),
+        hist = list(self._hist)
+        back = T * len(hist)
+        h = ppo_ops.her_relabel(torch.cat([x[0] for x in hist] + [self.pos[4:4 + T]]),
+                                torch.cat([x[1] for x in hist] + [self.term]),
+                                torch.cat([x[2] for x in hist] + [self.trunc]), hist[0][4],
+                                torch.cat([x[3] for x in hist] + [self.reward]), None,
+                                seed=self.her_seed, env_id0=self.engine.env_id0, step0=start - back, max_goals=max_goals)
+        keep = h["t"] >= back
+        self.her = dict(t=(h["t"][keep] - back).contiguous(), n=h["n"][keep].contiguous(), goal=h["goal"][keep].contiguous(),
                         reward=h["reward"][keep].contiguous(), done=h["done"][keep].contiguous())
         self.her["counts"] = torch.bincount(self.her["n"].long(), minlength=N).int()
         return self.her
@@ -199,20 +213,26 @@ class VecPPOTrainer:
         ag.actor.train(); ag.critic.train()
         la = lv = None
         local_steps = n_steps = -(-total // self.minibatch)
-        if ag.grad_sync is not None and torch.distributed.is_initialized():
+        synced = ag.grad_sync is not None and torch.distributed.is_initialized()
+        if synced:
             # relabelled-record counts differ per rank; every rank must take part in the same number of all-reduces
             m = torch.tensor([n_steps], device=self.device)
             torch.distributed.all_reduce(m, op=torch.distributed.ReduceOp.MAX)
             n_steps = int(m.item())
         for ep in range(ag.K_epochs):
             perm = (torch.randperm(total) if permutations is None else torch.as_tensor(permutations[ep])).to(self.device)
-            if n_steps > local_steps:                  # a rank with fewer records revisits samples of this epoch
-                perm = torch.cat([perm, perm.repeat(n_steps // local_steps + 1)])[:n_steps * self.minibatch]
+            if synced and n_steps > -(-perm.numel() // self.minibatch):
+                # a rank with fewer samples than its peers (relabelled-record counts differ) revisits samples of this
+                # epoch so that it issues exactly n_steps gradient all-reduces like every other rank
+                perm = perm[torch.arange(n_steps * self.minibatch, device=self.device) % perm.numel()]
+            done_steps = 0
             for i in range(0, perm.numel(), self.minibatch):
                 idx = perm[i:i + self.minibatch]
                 s0, p0 = self._stacks(smp_t[idx], smp_n[idx], after=False)
                 la, lv = ag.minibatch_step(s0, p0, self.goal_input(smp_goal[idx], False), act[idx],
                                            logp[idx].view(-1, 1), adv[idx].view(-1, 1), target[idx].view(-1, 1))
+                done_steps += 1
+            assert done_steps == n_steps or not synced, (done_steps, n_steps)
         if ag.use_lr_decay:
             ag.scheduler_actor.step(); ag.scheduler_critic.step()
         self.her = None

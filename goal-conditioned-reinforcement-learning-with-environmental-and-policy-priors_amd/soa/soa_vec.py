@@ -95,25 +95,35 @@ class VecSoATrainer(VecPPOTrainer):
         ag = self.agent
         t_idx, n_idx, goal2, disp = self.orientation_samples()
         total = t_idx.numel()
-        if total == 0:
-            return None
-        n_steps = -(-total // self.orient_minibatch)
-        if ag.grad_sync_orient is not None and torch.distributed.is_initialized():
+        local_steps = n_steps = -(-total // self.orient_minibatch)
+        synced = ag.grad_sync_orient is not None and torch.distributed.is_initialized()
+        if synced:
+            # EVERY rank joins this collective, also one without a single orientation sample (no success, no
+            # hindsight record): it then takes part in each gradient all-reduce with zero gradients
             m = torch.tensor([n_steps], device=self.device)
             torch.distributed.all_reduce(m, op=torch.distributed.ReduceOp.MAX)
             n_steps = int(m.item())
+        if n_steps == 0:
+            return None
         ag.agent_position_preditor.train()
         loss = None
         for ep in range(ag.K_epochs_pre_agent_position):
+            if total == 0:
+                for _ in range(n_steps):
+                    ag.orientation_idle_step()
+                continue
             perm = (torch.randperm(total) if permutations is None else torch.as_tensor(permutations[ep])).to(self.device)
-            if n_steps * self.orient_minibatch > perm.numel() + self.orient_minibatch - 1:
-                perm = perm.repeat(-(-n_steps * self.orient_minibatch // total))[:n_steps * self.orient_minibatch]
+            if synced and n_steps > -(-perm.numel() // self.orient_minibatch):
+                perm = perm[torch.arange(n_steps * self.orient_minibatch, device=self.device) % perm.numel()]
+            done_steps = 0
             for i in range(0, perm.numel(), self.orient_minibatch):
                 idx = perm[i:i + self.orient_minibatch]
                 s0, p0 = self._stacks(t_idx[idx], n_idx[idx], after=False)
                 with torch.no_grad():
                     x8 = ag.policy_input(s0)
                 loss = ag.orientation_step(x8, p0, goal2[idx], disp[idx])
+                done_steps += 1
+            assert done_steps == n_steps or not synced, (done_steps, n_steps)
         if ag.use_lr_decay:
             ag.scheduler_agent_position_preditor.step()
         return loss

@@ -96,7 +96,7 @@ def main(argv=None, predictor=False, soa=False):
 
     lo, hi = twdist.shard_range(args.num_envs, rank, world)
     variant = 4 if args.env.endswith("v4") else 6
-    engine = TwoarmyEngine(variant, hi - lo, 17, device=device, seed=seed or 0, env_id0=lo)
+    engine = TwoarmyEngine(variant, hi - lo, 17, device=device, seed=seed or 0, env_id0=lo, max_steps=args.max_steps)
     Trainer = VecSoATrainer if soa else VecPPOTrainer
     trainer = Trainer(agent, engine, args.rollout_steps, args.minibatch, frame_codes=args.frame_codes)
     her = str(args.her).lower() not in ("false", "0", "no")

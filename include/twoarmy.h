@@ -142,6 +142,36 @@ int tw_last_hip_error(void);
 const char *tw_last_error_message(void);
 const char *tw_version(void);
 
+/* Output buffers of one T-step rollout (or one step: T = 1) allocated by the engine in its native MI355X layout,
+ * all carved out of ONE device slab.  This is the counterpart of the arrays the reference's rollout loop appends to
+ * (soa/train_ppo.py:116-123 stack pushes, Buffer_gridworld.store env_buffer.py:68-77): every user of the library --
+ * the Python trainer, the vector env, a C caller -- gets the same placement without probing candidates.
+ * Float frames use the RECORD layout: one stream of 2048-byte blocks, one per env-step,
+ *   [T][N] x { float matrix[292] (289 + 3 zero pad) | uint8 image[880] (V*V*3 + zero pad) }
+ * i.e. matrix = slab, mat_pitch = 512 floats; obs = slab + 1168, obs_pitch = 2048 bytes.  tw_rollout recognises these
+ * pointers / pitches and writes every block with two full-wave stores of eight whole 128-byte lines each.  (Two
+ * separate streams, which the API still accepts, make the store bandwidth depend on where the driver happens to place
+ * them: 0.178 ... 0.220 ms per 4096 x 128 launch; the record stream is 0.19 ms on every allocation.)
+ * With TW_F_MATRIX_CODE: obs uint8 [T][N][880] and matrix uint8 [T][N][304] as two streams, mat_pitch in bytes.
+ *   pos float[T][N][2], reward float[T][N], terminated / truncated uint8[T][N]   (dense)
+ * `backing`: how the slab is backed -- 1 (default) = 2 MiB physical chunks (hipMemCreate) mapped into one virtual range,
+ * 0 = hipMalloc (also the fallback when the runtime refuses the mapping calls).  Pass the struct's members to tw_step / tw_rollout.  tw_free_outputs releases the slab
+ * (the struct is zeroed). */
+typedef struct tw_outputs {
+    uint8_t *obs;
+    void *matrix;
+    float *pos;
+    float *reward;
+    uint8_t *terminated;
+    uint8_t *truncated;
+    int obs_pitch, mat_pitch;
+    int T, n_envs, flags, device, backing;
+    uint64_t slab_bytes;
+    void *slab;
+} tw_outputs;
+int tw_alloc_outputs(tw_engine *e, int T, int flags, tw_outputs *out);
+int tw_free_outputs(tw_outputs *out);
+
 /* Time one launch of the engine kernel with hipEvents on `stream` (bench.py roofline leg):
  * runs tw_rollout `iters` times back-to-back and returns the mean kernel time in milliseconds. */
 int tw_time_rollout(tw_engine *e, int T, const int32_t *actions, uint8_t *obs, int obs_pitch,

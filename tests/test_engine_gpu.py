@@ -17,6 +17,11 @@ def _engine(*a, **k):
     return TwoarmyEngine(*a, **k)
 
 
+def padded_rows(t, nlead, width):
+    from twoarmy_amd.engine import padded_rows as f
+    return f(t, nlead, width)
+
+
 def _fields():
     from twoarmy_amd._lib import FIELDS
     return FIELDS
@@ -178,7 +183,7 @@ def test_matrix_code_step_api_and_pad():
     eng = _engine(6, 130, 17, seed=SEED)
     ref = _oracle(6, 130, 30, 17, 0)
     out = eng.alloc_outputs(matrix_codes=True)
-    raw = out["matrix"]._base
+    raw = padded_rows(out["matrix"], 1, 304)
     assert raw.shape[-1] == 304 and raw.dtype == torch.uint8
     acts = eng.fill_actions(30)
     for t in range(30):
@@ -265,11 +270,11 @@ def test_rollout_4096_vs_oracle(variant, dense, epw):
 def test_native_layout_pad_is_zero():
     eng = _engine(4, 130, 17, seed=SEED)
     out = eng.alloc_outputs(40)
-    out["obs"]._base.fill_(0xAB) if out["obs"]._base is not None else None
+    raw_o, raw_m = padded_rows(out["obs"], 2, 880), padded_rows(out["matrix"], 2, 292)
+    raw_o.fill_(0xAB)
+    raw_m.fill_(7.0)
     eng.rollout(40, out)
     torch.cuda.synchronize()
-    raw_o = out["obs"]._base if out["obs"]._base is not None else out["obs"]
-    raw_m = out["matrix"]._base if out["matrix"]._base is not None else out["matrix"]
     assert raw_o.shape[-1] == 880 and raw_m.shape[-1] == 292
     assert int(raw_o[..., 867:].max()) == 0
     assert float(raw_m[..., 289:].abs().max()) == 0.0
