@@ -72,7 +72,7 @@ def collect_windows(engine, n_records, rollout_steps=128):
             m[15 * 17 + 3] = 0.3
             init_frame = m.to(engine.device)
         acts = engine.fill_actions(T)                   # the engine's Philox stream: uniform over the 5 policy actions
-        out = engine.alloc_outputs(T, obs=False, dense=True)
+        out = engine.alloc_outputs(T)                   # native record layout -> the pipelined rollout kernel (one launch)
         engine.rollout(T, out, actions=acts, autoreset=True, policy_idx=True)
         w = windows_from_rollout(out["matrix"], out["pos"], acts, out["reward"], out["terminated"], out["truncated"],
                                  init_frame)

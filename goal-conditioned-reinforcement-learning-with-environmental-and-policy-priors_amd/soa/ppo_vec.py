@@ -44,6 +44,9 @@ class VecPPOTrainer:
         self.goal1 = torch.tensor([GOAL_YX], device=d)
         self.goal = self.goal1.expand(N, 2).contiguous()
         self.n_all = torch.arange(N, dtype=torch.int32, device=d)
+        # frame index of the newest frame of the acting state at step t (row t), for ppo_gather_stack
+        self.k_rows = (torch.arange(T + 1, dtype=torch.int32, device=d) + 3).view(-1, 1).expand(T + 1, N).contiguous()
+        self._zero_age = torch.zeros(N, dtype=torch.int32, device=d)
         self.init_pos = torch.tensor(INIT_POS, device=d)
         # the reset frame is a constant of the task: take it from a scratch engine step-free reset
         self.init_frame = self._reset_frame()
@@ -80,17 +83,15 @@ class VecPPOTrainer:
     @torch.no_grad()
     def collect(self, uniforms=None):
         T, N = self.T, self.N
+        step_out = [{"obs": None, "matrix": self.frames[t + 4], "pos": self.pos[t + 4], "reward": self.reward[t],
+                     "terminated": self.term[t], "truncated": self.trunc[t]} for t in range(T)]
         for t in range(T):
-            k = torch.full((N,), t + 3, dtype=torch.int32, device=self.device)
-            s4, p4 = ppo_ops.gather_stack(self.frames, self.pos, k, self.n_all, self.age[t], self.init_frame,
+            s4, p4 = ppo_ops.gather_stack(self.frames, self.pos, self.k_rows[t], self.n_all, self.age[t], self.init_frame,
                                           self.init_pos)
             a, logp = self.agent.act_batch(s4, p4, self.goal, None if uniforms is None else uniforms[t])
             self.action[t], self.logp[t] = a, logp
-            out = {"obs": None, "matrix": self.frames[t + 4], "pos": self.pos[t + 4], "reward": self.reward[t],
-                   "terminated": self.term[t], "truncated": self.trunc[t]}
-            self.engine.step(a, out, autoreset=True, policy_idx=True)
-            done = (self.term[t] | self.trunc[t]) != 0
-            self.age[t + 1] = torch.where(done, torch.zeros_like(self.age[t]), self.age[t] + 1)
+            self.engine.step(a, step_out[t], autoreset=True, policy_idx=True)
+            torch.where((self.term[t] | self.trunc[t]) != 0, self._zero_age, self.age[t] + 1, out=self.age[t + 1])
         self.env_steps += T * N
 
     def carry_over(self):

@@ -7,7 +7,16 @@ orientation sample of the next step (f[:,1]).  Here both are index arithmetic on
 the next step's f is f[t+1] (or f[t] again when the episode ends at t, which is what the reference's four terminal
 window shifts produce), and the 3-step displacement is pos[min(t+3, end+1)] - pos[t] inside the episode.
 The orientation head trains, like the reference (train_SoA.py:206-224, 243-262), only on trajectories that reach
-their goal: episodes that terminated, plus the hindsight records of the others."""
+their goal: episodes that terminated, plus the hindsight records of the others.
+
+Success replay (train_SoA.py:200-205, 243-262): the reference keeps the window records of the last 99 episodes that
+reached the goal in a FIFO that survives its buffer resets, and trains the orientation head on that FIFO at every
+update.  Here the FIFO holds materialised orientation samples (4-frame stacks, positions, goal, displacement) of
+goal-reaching episodes of EARLIER rollouts; an update trains on every goal-reaching episode of the current rollout
+plus the newest (99 - that number, if positive) episodes of the FIFO -- exactly the reference's "last 99 successes"
+whenever the current rollout holds at most 99 of them (its scale), and never fewer samples than the rollout offers."""
+import collections
+
 import torch
 
 from .. import ppo_ops
@@ -22,6 +31,8 @@ class VecSoATrainer(VecPPOTrainer):
         self.future = torch.zeros((T + 1, N, 2), dtype=torch.float32, device=self.device)     # f of the acting state t
         self.pending_future = None                       # f already drawn for the first state of the next rollout
         self.orient_minibatch = int(orient_minibatch or minibatch)
+        self.replay_episodes = 99                        # len(fp_terminate_buffer) > 99 -> pop(0), train_SoA.py:204-205
+        self._replay = collections.deque()               # oldest first; one dict of sample tensors per episode
 
     # ------------------------------------------------------------------ rollout
     @torch.no_grad()
@@ -74,6 +85,8 @@ class VecSoATrainer(VecPPOTrainer):
         t_idx, n_idx = torch.nonzero(success, as_tuple=True)
         u = end[t_idx, n_idx]
         goal2 = self.goal1.expand(t_idx.numel(), 2)
+        self._n_success_samples = int(t_idx.numel())
+        self._success_key = u * N + n_idx                                            # episode id: (end step, env)
         if self.her is not None and self.her["t"].numel():
             h = self.her
             hs = torch.nonzero(h["done"]).view(-1)                                   # last record of every relabelled prefix
@@ -91,10 +104,48 @@ class VecSoATrainer(VecPPOTrainer):
         p_fut = self.pos[torch.minimum(t_idx + 3, u + 1) + 3, n_idx]
         return t_idx.int(), n_idx.int(), goal2, p_fut - p_now
 
+    # ------------------------------------------------------------------ success replay (train_SoA.py:200-205)
+    @torch.no_grad()
+    def replay_samples(self, n_current_episodes):
+        """Materialised samples of the newest (replay_episodes - n_current_episodes) remembered episodes, or None."""
+        k = max(0, self.replay_episodes - int(n_current_episodes))
+        eps = list(self._replay)[-k:] if k else []
+        if not eps:
+            return None
+        return {key: torch.cat([e[key] for e in eps]) for key in ("s0", "p0", "goal2", "disp")}
+
+    @torch.no_grad()
+    def remember_successes(self, t_idx, n_idx, goal2, disp):
+        """Push the goal-reaching episodes of this rollout (the first _n_success_samples samples) into the FIFO in
+        completion order (end step, then env); only the newest `replay_episodes` are kept."""
+        ns = self._n_success_samples
+        if ns == 0:
+            return
+        keys, inv = torch.unique(self._success_key, return_inverse=True)              # ascending = completion order
+        first = max(0, keys.numel() - self.replay_episodes)
+        sel = torch.nonzero(inv >= first).view(-1)
+        s0, p0 = self._stacks(t_idx[:ns][sel], n_idx[:ns][sel], after=False)
+        ep = (inv[sel] - first).cpu()
+        order = torch.argsort(ep, stable=True)
+        counts = torch.bincount(ep, minlength=keys.numel() - first).tolist()
+        sel_o = order.to(self.device)
+        s0, p0, g2, dp = s0[sel_o], p0[sel_o], goal2[:ns][sel][sel_o], disp[:ns][sel][sel_o]
+        off = 0
+        for c in counts:
+            self._replay.append(dict(s0=s0[off:off + c].clone(), p0=p0[off:off + c].clone(),
+                                     goal2=g2[off:off + c].clone(), disp=dp[off:off + c].clone()))
+            off += c
+        while len(self._replay) > self.replay_episodes:
+            self._replay.popleft()
+
     def update_orientation(self, permutations=None):
         ag = self.agent
         t_idx, n_idx, goal2, disp = self.orientation_samples()
-        total = t_idx.numel()
+        n_rollout = t_idx.numel()
+        n_cur_eps = int(torch.unique(self._success_key).numel()) if self._n_success_samples else 0
+        rep = self.replay_samples(n_cur_eps)
+        n_rep = 0 if rep is None else int(rep["disp"].shape[0])
+        total = n_rollout + n_rep                            # sample ids: [0, n_rollout) rollout, then the replay
         local_steps = n_steps = -(-total // self.orient_minibatch)
         synced = ag.grad_sync_orient is not None and torch.distributed.is_initialized()
         if synced:
@@ -118,14 +169,21 @@ class VecSoATrainer(VecPPOTrainer):
             done_steps = 0
             for i in range(0, perm.numel(), self.orient_minibatch):
                 idx = perm[i:i + self.orient_minibatch]
-                s0, p0 = self._stacks(t_idx[idx], n_idx[idx], after=False)
+                cur = idx[idx < n_rollout]
+                s0, p0 = self._stacks(t_idx[cur], n_idx[cur], after=False)
+                g2, dp = goal2[cur], disp[cur]
+                if n_rep:
+                    old = idx[idx >= n_rollout] - n_rollout
+                    s0, p0 = torch.cat([s0, rep["s0"][old]]), torch.cat([p0, rep["p0"][old]])
+                    g2, dp = torch.cat([g2, rep["goal2"][old]]), torch.cat([dp, rep["disp"][old]])
                 with torch.no_grad():
                     x8 = ag.policy_input(s0)
-                loss = ag.orientation_step(x8, p0, goal2[idx], disp[idx])
+                loss = ag.orientation_step(x8, p0, g2, dp)
                 done_steps += 1
             assert done_steps == n_steps or not synced, (done_steps, n_steps)
         if ag.use_lr_decay:
             ag.scheduler_agent_position_preditor.step()
+        self.remember_successes(t_idx, n_idx, goal2, disp)
         return loss
 
     def update(self, permutations=None, orient_permutations=None):

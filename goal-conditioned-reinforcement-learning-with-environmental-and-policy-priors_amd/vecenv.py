@@ -28,7 +28,8 @@ class TwoarmyVecEnv:
         self.engine = TwoarmyEngine(self.variant, num_envs, agent_view_size, device=device, seed=seed, env_id0=env_id0)
         self.device = self.engine.device
         self._out = self.engine.alloc_outputs()
-        self._init_obs = self.engine.alloc_outputs()["obs"]
+        self._init_obs = torch.empty((self.num_envs, agent_view_size, agent_view_size, 3), dtype=torch.uint8,
+                                     device=self.device)
         self.engine.reset(obs=self._init_obs)                      # the reset observation is a constant of the task
         self.goal_yx = torch.tensor([2.0, 14.0], device=self.device).expand(self.num_envs, 2)
         self.single_observation_shape = (agent_view_size, agent_view_size, 3)

@@ -1,0 +1,116 @@
+"""SURVEY 8 rows a15 and f4 ON THE GPU: the predictor path (MIOpen conv / BatchNorm / ConvTranspose, the 3 x 1024
+LSTM on rocBLAS, 8-frame actor / critic) and the offline world-model training, against the numbers recorded from
+the reference (tests/golden/predictor.npz, pretrain.npz) -- the same checks tests/test_predictor_cpu.py and
+tests/test_pretrain_cpu.py run on the CPU.
+
+Tolerances (stated here because fp32 GEMM / conv reduction order differs between MIOpen / rocBLAS and the CPU run
+that produced the goldens): forward outputs rtol 2e-5 / atol 2e-6 (values of O(1)), per-update losses atol 1e-5
+(north_star's loss tolerance)."""
+import numpy as np
+import pytest
+import torch
+
+from test_ppo_common import GOLDEN
+from test_predictor_cpu import check_pred_states_and_heads
+from test_pretrain_cpu import check_offline_world_model_training
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_pred_states_and_heads_match_reference_on_gpu():
+    check_pred_states_and_heads(DEV, 2.0)
+
+
+def test_predictor_sampler_and_update_on_gpu_match_cpu_torch():
+    """ppo_predictor.select_action / update (PPO_Predictor.py:85-193) on the device: the 8-frame inputs are the golden
+    ones; log-prob of the HIP sampler == log(probs[a]) of the reference's forward, and one update step's losses ==
+    the same step evaluated with plain torch on the CPU (fp32, tolerance 1e-5)."""
+    from twoarmy_amd import ppo_ops
+    agent, x, p, goal = check_pred_states_and_heads(DEV, 2.0)
+    g = dict(np.load(GOLDEN + "/predictor.npz"))
+    probs = torch.tensor(g["probs"], device=DEV)
+    u = torch.tensor([0.05, 0.5, 0.95], device=DEV)
+    a, logp = ppo_ops.sample(probs, u)
+    import ppo_oracle as po
+    want_a, want_logp = po.sample(g["probs"], u.cpu().numpy())
+    assert np.array_equal(a.cpu().numpy(), want_a)
+    np.testing.assert_allclose(logp.cpu().numpy(), want_logp, rtol=1e-6, atol=1e-6)
+    # one minibatch step on the device vs a literal torch evaluation of PPO_Predictor.py:136-176 on the CPU
+    adv = torch.tensor([[0.3], [-0.2], [0.05]], device=DEV)
+    tgt = torch.tensor([[0.1], [0.4], [-0.3]], device=DEV)
+    old = logp.view(-1, 1) - 0.02
+    import copy
+    actor_cpu, critic_cpu = copy.deepcopy(agent.actor).cpu(), copy.deepcopy(agent.critic).cpu()
+    agent.actor.train(); agent.critic.train()
+    la, lv = agent.minibatch_step_x(x, p, goal, a, old, adv, tgt)
+    actor_cpu.train(); critic_cpu.train()
+    pc = actor_cpu(x.cpu(), p.cpu(), goal.cpu())
+    dist = torch.distributions.Categorical(probs=pc)
+    ratio = torch.exp(dist.log_prob(a.cpu().long()).view(-1, 1) - old.cpu())
+    s1, s2 = ratio * adv.cpu(), torch.clamp(ratio, 0.9, 1.1) * adv.cpu()
+    want_la = (-torch.min(s1, s2) - 0.01 * dist.entropy().view(-1, 1)).mean()
+    want_lv = torch.nn.functional.smooth_l1_loss(critic_cpu(x.cpu(), p.cpu(), goal.cpu()), tgt.cpu())
+    assert abs(float(la) - float(want_la)) < 1e-5 and abs(float(lv) - float(want_lv)) < 1e-5
+
+
+def _world_model(seed0=31):
+    from twoarmy_amd.soa.agent.encoder_LSTM_decoder import encoder_lstm_decoder
+    from test_predictor_cpu import det_weights_v2
+    torch.manual_seed(9981)
+    m = encoder_lstm_decoder()
+    for i, net in enumerate((m.encoder, m.decoder)):
+        net.load_state_dict(det_weights_v2(net, seed0 + i))
+    sd = {}
+    for k, (name, prm) in enumerate(m.predictor.state_dict().items()):
+        n = prm.numel()
+        sd[name] = torch.tensor((0.03 * np.sin(0.37 * np.arange(n, dtype=np.float64) + 1.3 * k)).reshape(tuple(prm.shape)),
+                                dtype=prm.dtype)
+    m.predictor.load_state_dict(sd)
+    return m
+
+
+@pytest.mark.parametrize("stage", ["autoencoder", "predictor"])
+def test_offline_losses_and_gradients_on_gpu_equal_cpu_at_identical_weights(stage):
+    """One training step of each offline stage (encoder_LSTM_decoder.py:120-135 / :226-240) at IDENTICAL weights and
+    minibatch: the loss on the device within 1e-5 of the CPU's; every parameter gradient within 1e-2 relative L2 of the
+    CPU's (train mode: BatchNorm batch statistics, MIOpen conv / conv-transpose backward, the 3 x 1024 LSTM backward).
+    The gradient tolerance is what stock MIOpen delivers, not a property of code in this repository: the CPU fp32
+    gradients are within 3e-5 of an fp64 evaluation, MIOpen's reach 2.5e-3 on the encoder's first conv (three
+    train-mode BatchNorm backward passes amplify their rounding); conv biases in front of a BatchNorm have an exactly
+    zero gradient, hence the absolute floor."""
+    g = dict(np.load(GOLDEN + "/pretrain.npz"))
+    res = {}
+    for dev in ("cpu", DEV):
+        m = _world_model()
+        nets = (m.encoder, m.decoder) if stage == "autoencoder" else (m.predictor,)
+        for net in (m.encoder, m.decoder, m.predictor):
+            net.to(dev)
+            net.train()
+        if stage == "autoencoder":
+            loss = m._recon_loss(torch.tensor(g["buf_s"][:8, 4].reshape(-1, 1, 289), device=dev))
+        else:
+            m.encoder.eval(); m.decoder.eval()
+            loss = m._predictor_loss(torch.tensor(g["buf_s"][:8], device=dev))
+        loss.backward()
+        res[dev] = (float(loss), [p.grad.detach().cpu().double() for net in nets for p in net.parameters()])
+    assert abs(res["cpu"][0] - res[DEV][0]) < 1e-5
+    rel = []
+    for a, b in zip(res["cpu"][1], res[DEV][1]):
+        if float(a.norm()) < 1e-4:          # analytically zero (conv bias in front of BatchNorm): only rounding noise
+            assert float(b.norm()) < 5e-2
+        else:
+            rel.append(float((a - b).norm()) / float(a.norm()))
+    print("relative L2 gradient differences cpu vs gpu:", ["%.1e" % r for r in rel])
+    assert max(rel) <= 1e-2, rel
+
+
+def test_offline_world_model_training_matches_reference_on_gpu():
+    """Whole two-stage training on the device vs the losses the reference logged (CPU run).  Adam(eps = 1e-9) turns
+    every near-zero gradient element into a full +-lr step, so reduction-order differences between MIOpen and the
+    CPU kernels compound from step to step: the first two steps of each stage (nothing compounded yet) must agree
+    within 1e-5 (stage 2: 1e-4, it starts from stage 1's already drifted encoder), the 12-step trajectories within 5e-4
+    for the auto-encoder (observed 1.4e-4) and 5e-3 for the 25 M-parameter LSTM (observed 2.6e-3); the per-step
+    1e-5 claim is carried by test_offline_losses_and_gradients_on_gpu_equal_cpu_at_identical_weights."""
+    torch.backends.cudnn.deterministic = True
+    check_offline_world_model_training(DEV, 5e-4, atol_first=1e-5, atol_pre=5e-3)

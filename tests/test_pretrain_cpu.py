@@ -7,7 +7,9 @@ from test_ppo_common import GOLDEN
 from test_predictor_cpu import det_weights_v2
 
 
-def test_offline_world_model_training_matches_reference():
+def check_offline_world_model_training(device, atol, atol_first=None, n_first=2, atol_pre=None):
+    """update_encoder_decoder / update_predictor (encoder_LSTM_decoder.py:95-290) on `device`: every train and
+    validation loss of both stages vs the losses the reference logged on the same 48 records."""
     from twoarmy_amd.soa.agent.encoder_LSTM_decoder import encoder_lstm_decoder
     g = dict(np.load(GOLDEN + "/pretrain.npz"))
     torch.manual_seed(9981)
@@ -32,17 +34,29 @@ def test_offline_world_model_training_matches_reference():
     buf = np.zeros(g["buf_s"].shape[0], dtype=np.dtype([("s", np.float32, (9, 289))]))
     buf["s"] = g["buf_s"]
     torch.manual_seed(111)
-    m.update_encoder_decoder(buf, "cpu")
+    m.update_encoder_decoder(buf, device)
     sc = m.en_de_writer.scalars
-    np.testing.assert_allclose([v for _, v in sc["loss/en_de_train_loss_update"]], g["ed_train"], rtol=0, atol=1e-5)
-    np.testing.assert_allclose([v for _, v in sc["loss/en_de_value_loss_update"]], g["ed_val"], rtol=0, atol=1e-5)
+    if atol_first is not None:          # before optimiser-step differences have compounded: the tight tolerance
+        np.testing.assert_allclose([v for _, v in sc["loss/en_de_train_loss_update"]][:n_first], g["ed_train"][:n_first],
+                                   rtol=0, atol=atol_first)
+    np.testing.assert_allclose([v for _, v in sc["loss/en_de_train_loss_update"]], g["ed_train"], rtol=0, atol=atol)
+    np.testing.assert_allclose([v for _, v in sc["loss/en_de_value_loss_update"]], g["ed_val"], rtol=0, atol=atol)
     torch.manual_seed(222)
-    m.update_predictor(buf, "cpu")
+    m.update_predictor(buf, device)
     sc = m.writer.scalars
-    np.testing.assert_allclose([v for _, v in sc["loss/pre_train_loss_update"]], g["pre_train"], rtol=0, atol=1e-5)
-    np.testing.assert_allclose([v for _, v in sc["loss/pre_value_loss_update"]], g["pre_val"], rtol=0, atol=1e-5)
-    np.testing.assert_allclose([float(v.double().sum()) for v in m.predictor.state_dict().values()],
-                               g["final_predictor_sum"], rtol=1e-5, atol=1e-4)
+    if atol_first is not None:
+        np.testing.assert_allclose([v for _, v in sc["loss/pre_train_loss_update"]][:n_first], g["pre_train"][:n_first],
+                                   rtol=0, atol=atol_first * 10)     # the stage starts from stage 1's (drifted) encoder
+    np.testing.assert_allclose([v for _, v in sc["loss/pre_train_loss_update"]], g["pre_train"], rtol=0, atol=atol_pre or atol)
+    np.testing.assert_allclose([v for _, v in sc["loss/pre_value_loss_update"]], g["pre_val"], rtol=0, atol=atol_pre or atol)
+    if atol <= 1e-5:        # parameter checksums only for the bit-reproducible (CPU) run: Adam(eps=1e-9) steps every
+        #                     near-zero-gradient element by +-lr, so sums over 4 M elements are chaotic across hardware
+        np.testing.assert_allclose([float(v.double().sum()) for v in m.predictor.state_dict().values()],
+                                   g["final_predictor_sum"], rtol=1e-5, atol=1e-4)
+
+
+def test_offline_world_model_training_matches_reference():
+    check_offline_world_model_training("cpu", 1e-5)
 
 
 def test_window_records_equal_literal_window_shifts():

@@ -153,3 +153,81 @@ def test_train_soa_entry_point_smoke():
                          "--minibatch", "256", "--updates", "2", "--k_epochs", "1", "--k_epochs_orientation", "1",
                          "--her", "False", "--cuda", "cuda:0"])
     assert tr.env_steps == 2 * 60 * 32 and tr.agent.agent_position_preditor.Px.out_features == 7
+
+
+def test_success_replay_equals_literal_fifo_of_99_episodes():
+    """The orientation head's success replay across updates (train_SoA.py:200-205: fp_terminate_buffer, FIFO of the
+    last 99 goal-reaching episodes, never cleared by the buffer reset) vs a literal construction: synthetic rollouts
+    with random episode structure are written into the trainer; after every "update" the trained sample set
+    (current goal-reaching episodes + replay) must equal, as a multiset of (displacement, acting position) rows, the
+    literal FIFO's content -- and, when a rollout alone holds more than 99 successes, every one of them."""
+    import collections
+    from twoarmy_amd.engine import TwoarmyEngine
+    from twoarmy_amd.soa.soa_vec import VecSoATrainer
+    rng = np.random.RandomState(7)
+    init_p = np.array([15.0, 3.0], np.float32)
+
+    def run(N, T, n_rollouts, p_term):
+        eng = TwoarmyEngine(6, N, 17, seed=9981)
+        tr = VecSoATrainer(seeded_agent(), eng, rollout_steps=T, minibatch=512, value_chunk=512)
+        fifo = collections.deque()
+        age0 = np.zeros(N, np.int64)
+        seen_big = False
+        for r in range(n_rollouts):
+            term = np.zeros((T, N), np.uint8); trunc = np.zeros((T, N), np.uint8)
+            pos = rng.randint(1, 16, size=(T + 4, N, 2)).astype(np.float32)
+            pos[:4] = tr.pos[:4].cpu().numpy() if r else init_p
+            age = np.zeros((T + 1, N), np.int64); age[0] = age0
+            for n in range(N):
+                t = 0
+                left = rng.randint(4, 18) - min(int(age0[n]), 3)
+                for t in range(T):
+                    left -= 1
+                    if left <= 0:
+                        (term if rng.rand() < p_term else trunc)[t, n] = 1
+                        left = rng.randint(4, 18)
+                    age[t + 1, n] = 0 if (term[t, n] or trunc[t, n]) else age[t, n] + 1
+            tr.term.copy_(torch.tensor(term)); tr.trunc.copy_(torch.tensor(trunc))
+            tr.pos.copy_(torch.tensor(pos)); tr.age.copy_(torch.tensor(age, dtype=torch.int32))
+            tr.her = None
+            # --- literal: goal-reaching episodes of this rollout in completion order
+            eps = []
+            for n in range(N):
+                start = 0
+                for t in range(T):
+                    if term[t, n] or trunc[t, n]:
+                        if term[t, n]:
+                            rows = []
+                            for s in range(start, t + 1):
+                                p_now = init_p if age[s, n] == 0 else pos[s + 3, n]
+                                p_fut = pos[min(s + 3, t + 1) + 3, n]
+                                rows.append(tuple(np.concatenate([p_fut - p_now, p_now]).tolist()))
+                            eps.append(((t, n), rows))
+                        start = t + 1
+            eps.sort(key=lambda e: e[0])
+            n_cur = len(eps)
+            for e in eps:
+                fifo.append(e[1])
+                if len(fifo) > 99:
+                    fifo.popleft()
+            want = [row for e in (fifo if n_cur <= 99 else [x[1] for x in eps]) for row in e]
+            # --- trainer
+            t_idx, n_idx, goal2, disp = tr.orientation_samples()
+            assert tr._n_success_samples == sum(len(e[1]) for e in eps)
+            rep = tr.replay_samples(n_cur)
+            s0, p0 = tr._stacks(t_idx, n_idx, after=False)
+            got = torch.cat([disp, p0[:, 3]], 1).cpu().numpy().tolist()
+            if rep is not None:
+                got += torch.cat([rep["disp"], rep["p0"][:, 3]], 1).cpu().numpy().tolist()
+                assert bool((rep["goal2"] == tr.goal1).all())
+            assert sorted(map(tuple, got)) == sorted(want), (r, n_cur, len(got), len(want))
+            seen_big |= n_cur > 99
+            tr.remember_successes(t_idx, n_idx, goal2, disp)
+            assert len(tr._replay) == min(99, len(fifo)) and len(tr._replay) <= 99
+            tr.carry_over()
+            age0 = age[T]
+        eng.close()
+        return seen_big
+
+    assert not run(N=6, T=60, n_rollouts=6, p_term=0.5)          # < 99 successes per rollout: the FIFO spans several updates
+    assert run(N=64, T=60, n_rollouts=2, p_term=0.9)             # > 99 successes in one rollout: all of them train

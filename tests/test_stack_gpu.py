@@ -105,9 +105,10 @@ def test_rollout_stacks_equal_reference_style_stacks():
     eng.close()
 
 
-def test_frame_codes_trainer_is_bit_identical():
-    """Storing the rollout as uint8 code frames (ppo_gather_stack_u8) changes nothing: same actions, same
-    stacks, same losses as the float-frame trainer."""
+def test_frame_codes_trainer_inputs_bit_identical_losses_1e5():
+    """Storing the rollout as uint8 code frames (ppo_gather_stack_u8): the actions and every policy input are
+    BIT-identical to the float-frame trainer's; the update losses agree within 1e-5 (MIOpen's conv backward
+    accumulates in a run-dependent order, so two runs on identical inputs are themselves only equal to ~2e-6)."""
     from twoarmy_amd.engine import TwoarmyEngine
     from twoarmy_amd.soa.agent.PPO import PPO
     from twoarmy_amd.soa.ppo_vec import VecPPOTrainer
@@ -246,3 +247,67 @@ def test_offline_world_model_pipeline_end_to_end(tmp_path):
     agent.load_world_model(torch.load(ck2[0], map_location="cpu", weights_only=True))
     assert torch.equal(agent.predictor.state_dict()["recurrent_model.weight_ih_l0"],
                        p.predictor.state_dict()["recurrent_model.weight_ih_l0"].cpu())
+
+
+def test_full_size_config2_collect_replay_and_minibatch():
+    """BASELINE configs[2] at FULL size (4096 envs x 128 steps, v6) through VecPPOTrainer.collect with the actor in
+    the loop, then size-independent checks:
+      * replaying the recorded actions through ONE pipelined tw_rollout launch from a fresh engine reproduces every
+        frame / position / reward / done flag of the per-step collection bit for bit (record layout, fast kernel);
+      * rewards take only the reference's five values, age counts steps since reset;
+      * one PPO minibatch (32768 samples, both networks): the fused HIP loss equals the numpy oracle's loss on the
+        same probabilities / values within 1e-5."""
+    import ppo_oracle as po
+    from twoarmy_amd import ppo_ops
+    from twoarmy_amd.engine import TwoarmyEngine
+    from twoarmy_amd.soa.agent.PPO import PPO
+    from twoarmy_amd.soa.ppo_vec import VecPPOTrainer
+    N, T, MB = 4096, 128, 32768
+    torch.manual_seed(9981)
+    eng = TwoarmyEngine(6, N, 17, seed=SEED)
+    agent = PPO()
+    agent.K_epochs = 1
+    tr = VecPPOTrainer(agent, eng, rollout_steps=T, minibatch=MB)
+    tr.collect()
+    torch.cuda.synchronize()
+    # --- replay through the pipelined kernel
+    eng2 = TwoarmyEngine(6, N, 17, seed=SEED)
+    out = eng2.alloc_outputs(T)
+    eng2.rollout(T, out, actions=tr.action.contiguous(), autoreset=True, policy_idx=True)
+    torch.cuda.synchronize()
+    assert torch.equal(out["matrix"], tr.frames[4:4 + T])
+    assert torch.equal(out["pos"], tr.pos[4:4 + T])
+    assert torch.equal(out["reward"], tr.reward) and torch.equal(out["terminated"], tr.term)
+    assert torch.equal(out["truncated"], tr.trunc)
+    a, b = eng.get_state(), eng2.get_state()
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    # --- properties
+    vals = torch.tensor([-0.01, -0.1, -0.9, 0.2, 0.9], device=tr.device)
+    assert bool((tr.reward.view(-1, 1) == vals.view(1, -1)).any(1).all())
+    done = (tr.term | tr.trunc) != 0
+    assert int(done.sum()) > N                                   # every env finished at least one episode on average
+    age = tr.age.cpu().numpy(); d = done.cpu().numpy()
+    assert np.array_equal(age[1:], np.where(d, 0, age[:-1] + 1)) and age.max() < 50
+    # --- one full-size minibatch
+    idx = torch.randperm(T * N, device=tr.device)[:MB]
+    t_idx, n_idx = (idx // N).int(), (idx % N).int()
+    s0, p0 = tr._stacks(t_idx, n_idx, after=False)
+    goal = tr.goal1.expand(MB, 2).contiguous()
+    agent.actor.train(); agent.critic.train()
+    with torch.no_grad():
+        probs = agent.actor_probs(s0, p0, goal)
+        value = agent.critic_value(s0, p0, goal)
+    act = tr.action.view(-1)[idx.long()]
+    logp = tr.logp.view(-1)[idx.long()].view(-1, 1)
+    adv = torch.randn(MB, 1, device=tr.device) * 0.1
+    tgt = torch.randn(MB, 1, device=tr.device) * 0.1
+    la, lv = agent.minibatch_step(s0, p0, goal, act, logp, adv, tgt)
+    q, logits, ent = po.categorical(probs.cpu().numpy())
+    lp = logits[np.arange(MB), act.cpu().numpy()].reshape(-1, 1)
+    ratio = np.exp(lp - logp.cpu().numpy())
+    advn = adv.cpu().numpy()
+    want_la = float(np.mean(-np.minimum(ratio * advn, np.clip(ratio, 0.9, 1.1) * advn) - 0.01 * ent.reshape(-1, 1), dtype=np.float64))
+    dv = value.cpu().numpy() - tgt.cpu().numpy()
+    want_lv = float(np.mean(np.where(np.abs(dv) < 1, 0.5 * dv * dv, np.abs(dv) - 0.5), dtype=np.float64))
+    assert abs(float(la) - want_la) < 1e-5 and abs(float(lv) - want_lv) < 1e-5
+    eng.close(); eng2.close()
