@@ -127,6 +127,8 @@ def build_parser():
     ap.add_argument("--k-epochs", type=int, default=1)
     ap.add_argument("--amp", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--her", action="store_true")
+    ap.add_argument("--nchw", action="store_true", help="ppo mode: literal NCHW nn.Sequential conv stacks (default: channels-last "
+                    "+ fused epilogues)")
     ap.add_argument("--predictor", action="store_true", help="ppo mode: PPO + predictor head (configs[4])")
     ap.add_argument("--rehearse", action="store_true",
                     help="launcher / process-group plumbing only, no engine (for CPU-only hosts: gloo); the line "
@@ -346,6 +348,8 @@ def run_ppo_mode(args, rank, world, dev, coll):
     agent.sample_seed = SEED + 7919 * rank
     agent.amp_dtype = torch.bfloat16 if args.amp == "bf16" else None
     agent.to(dev)
+    if not args.nchw:
+        agent.use_nhwc()
     twdist.broadcast_parameters([agent.actor, agent.critic])
     sync_ms = []
     bucket = None

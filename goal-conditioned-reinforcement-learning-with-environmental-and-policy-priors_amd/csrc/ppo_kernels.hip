@@ -61,6 +61,59 @@ __global__ void ppo_sample_kernel(const float *__restrict__ probs, int B, const 
     logp[b] = logf(fminf(fmaxf(qa, CAT_EPS), 1.0f - CAT_EPS));
 }
 
+// ------------------------------------------------------------------ conv epilogues (channels-last activations)
+// The conv GEMMs stay in MIOpen; what PyTorch wraps around each of them -- output.add_(bias) (one pass), ReLU
+// (another pass), and in backward threshold_backward (one pass) + the bias-gradient reduction (one pass) -- are pure
+// HBM passes over the biggest tensors of the update (33x33x64 floats per sample after conv1).  These two kernels do
+// each pair in ONE pass.  Activations are channels-last: element i belongs to channel i % C, C % 4 == 0.
+__global__ __launch_bounds__(256) void ppo_bias_relu_kernel(float4 *__restrict__ y, const float4 *__restrict__ bias,
+                                                            size_t n4, int c4) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 v = y[i];
+        const float4 b = bias[i % c4];
+        v.x = fmaxf(v.x + b.x, 0.f); v.y = fmaxf(v.y + b.y, 0.f);
+        v.z = fmaxf(v.z + b.z, 0.f); v.w = fmaxf(v.w + b.w, 0.f);
+        y[i] = v;
+    }
+}
+
+// gx = gy * (y > 0), partial[block][C] = sum over the block's pixels of gx.  Block = 256 threads laid out as
+// (256 / c4) pixel rows x c4 channel quads, walking `pixels_per_block` consecutive pixels; the per-thread sums are
+// combined through LDS in a fixed order (deterministic), the caller adds the per-block partials.
+__global__ __launch_bounds__(256) void ppo_relu_bwd_bias_grad_kernel(const float4 *__restrict__ gy,
+                                                                     const float4 *__restrict__ y,
+                                                                     float4 *__restrict__ gx,
+                                                                     float4 *__restrict__ partial, size_t n_pixels,
+                                                                     int c4, int pixels_per_block) {
+    __shared__ float4 red[256];
+    const int rows = 256 / c4;                        // pixel rows handled side by side (c4 <= 64)
+    const int cq = threadIdx.x % c4, row = threadIdx.x / c4;
+    const size_t p0 = (size_t)blockIdx.x * pixels_per_block;
+    const size_t p1 = p0 + pixels_per_block < n_pixels ? p0 + pixels_per_block : n_pixels;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < rows) {
+        for (size_t px = p0 + row; px < p1; px += rows) {
+            const size_t i = px * c4 + cq;
+            const float4 g = gy[i], v = y[i];
+            float4 o;
+            o.x = v.x > 0.f ? g.x : 0.f; o.y = v.y > 0.f ? g.y : 0.f;
+            o.z = v.z > 0.f ? g.z : 0.f; o.w = v.w > 0.f ? g.w : 0.f;
+            gx[i] = o;
+            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (row == 0) {
+        for (int r = 1; r < rows; ++r) {
+            const float4 o = red[r * c4 + cq];
+            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+        }
+        partial[(size_t)blockIdx.x * c4 + cq] = acc;
+    }
+}
+
 // ------------------------------------------------------------------ GAE: segmented reverse scan
 // Block = 256 threads = 4 waves, GN envs (columns) x chunks of 64 time steps walked from T backwards (GN = 16 for
 // N < 16384 so that a 4096-env rollout still fills 256 workgroups; 64 otherwise).
@@ -485,6 +538,33 @@ int ppo_age_scan(const uint8_t *terminated, const uint8_t *truncated, const int3
     if (!terminated || !truncated || !age0 || !age || T <= 0 || N <= 0) return TW_E_ARG;
     hipLaunchKernelGGL(ppo_age_scan_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, terminated,
                        truncated, age0, T, N, age);
+    return check_launch();
+}
+
+int ppo_bias_relu_nhwc(float *y, const float *bias, int64_t n_pixels, int C, void *stream) {
+    if (!y || !bias || n_pixels <= 0 || C <= 0 || (C & 3) || ((uintptr_t)y & 15u) || ((uintptr_t)bias & 15u)) return TW_E_ARG;
+    const size_t n4 = (size_t)n_pixels * (C / 4);
+    const int grid = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(ppo_bias_relu_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<float4 *>(y),
+                       reinterpret_cast<const float4 *>(bias), n4, C / 4);
+    return check_launch();
+}
+
+int ppo_relu_bwd_bias_grad_nhwc_blocks(int64_t n_pixels, int C) {
+    if (n_pixels <= 0 || C <= 0 || (C & 3) || C > 256) return TW_E_ARG;
+    const int64_t want = (n_pixels + 511) / 512;              // >= 512 pixels per block
+    return (int)(want < 4096 ? want : 4096);
+}
+
+int ppo_relu_bwd_bias_grad_nhwc(const float *gy, const float *y, float *gx, float *partial, int64_t n_pixels, int C,
+                                void *stream) {
+    const int blocks = ppo_relu_bwd_bias_grad_nhwc_blocks(n_pixels, C);
+    if (blocks <= 0 || !gy || !y || !gx || !partial || (((uintptr_t)gy | (uintptr_t)y | (uintptr_t)gx | (uintptr_t)partial) & 15u))
+        return TW_E_ARG;
+    const int ppb = (int)((n_pixels + blocks - 1) / blocks);
+    hipLaunchKernelGGL(ppo_relu_bwd_bias_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4 *>(gy), reinterpret_cast<const float4 *>(y),
+                       reinterpret_cast<float4 *>(gx), reinterpret_cast<float4 *>(partial), (size_t)n_pixels, C / 4, ppb);
     return check_launch();
 }
 

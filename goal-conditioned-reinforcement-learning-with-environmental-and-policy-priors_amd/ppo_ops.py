@@ -134,3 +134,42 @@ def her_relabel(pos, terminated, truncated, age0, reward, choices=None, seed=0, 
         _lib.check(fn(*args, _p(offsets), _p(counts), _p(out["t"]), _p(out["n"]), _p(out["goal"]), _p(out["reward"]),
                       _p(out["done"]), _stream(pos)), "ppo_her_relabel")
     return out
+
+
+class _ConvBiasReLU(torch.autograd.Function):
+    """relu(conv2d(x, w) + b) on channels-last fp32 tensors: the conv (and its two backward GEMMs) in MIOpen, bias +
+    ReLU and ReLU-backward + bias-gradient as ONE pass each (ppo_bias_relu_nhwc / ppo_relu_bwd_bias_grad_nhwc) instead
+    of the add / clamp / threshold_backward / sum passes PyTorch runs around a Conv2d + ReLU pair."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride):
+        y = torch.ops.aten.convolution(x, w, None, list(stride), [0, 0], [1, 1], False, [0, 0], 1)
+        assert y.is_contiguous(memory_format=torch.channels_last), "conv epilogue kernels need channels-last activations"
+        B, Cc, H, W = y.shape
+        _lib.check(_lib.lib().ppo_bias_relu_nhwc(C.c_void_p(y.data_ptr()), _p(b.detach(), torch.float32), B * H * W, Cc,
+                                                 _stream(y)), "ppo_bias_relu_nhwc")
+        ctx.save_for_backward(x, w, y)
+        ctx.stride = list(stride)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        B, Cc, H, W = y.shape
+        npix = B * H * W
+        blocks = _lib.lib().ppo_relu_bwd_bias_grad_nhwc_blocks(npix, Cc)
+        g = torch.empty_like(y)                                   # channels-last like y
+        partial = torch.empty((blocks, Cc), dtype=torch.float32, device=y.device)
+        _lib.check(_lib.lib().ppo_relu_bwd_bias_grad_nhwc(C.c_void_p(gy.data_ptr()), C.c_void_p(y.data_ptr()),
+                                                          C.c_void_p(g.data_ptr()), _p(partial), npix, Cc, _stream(y)),
+                   "ppo_relu_bwd_bias_grad_nhwc")
+        gx, gw, _ = torch.ops.aten.convolution_backward(g, x, w, None, ctx.stride, [0, 0], [1, 1], False, [0, 0], 1,
+                                                        [bool(ctx.needs_input_grad[0]), True, False])
+        return gx, gw, partial.sum(0), None
+
+
+def conv_bias_relu(x, weight, bias, stride):
+    """relu(conv2d(x, weight, bias, stride)) for channels-last fp32 device tensors (see _ConvBiasReLU)."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
+    return _ConvBiasReLU.apply(x, weight, bias, tuple(stride))

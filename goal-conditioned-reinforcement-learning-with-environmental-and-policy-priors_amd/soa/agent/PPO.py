@@ -120,6 +120,17 @@ class PPO:
         self.actor.to(device); self.critic.to(device)
         return self
 
+    def trainable_nets(self):
+        return [self.actor, self.critic]
+
+    def use_nhwc(self, enable=True):
+        """Channels-last conv stacks + fused conv epilogues (all_net.TINet.nhwc): the fast layout on MI355X (no MIOpen
+        transposes, MFMA backward-data kernels).  Same arithmetic up to the summation order inside the conv GEMMs; the
+        default (NCHW, plain nn.Sequential) stays the literal parity mode.  Call after .to(device)."""
+        from .net.all_net import use_nhwc
+        use_nhwc(self.trainable_nets(), enable)
+        return self
+
     def select_action(self, state_matrix, states_stack, goal, device):
         """Reference signature (PPO.py:73-92): 5-deep numpy stacks in, python (action, log-prob) out."""
         sm = torch.as_tensor(np.asarray(state_matrix)[1:5], dtype=torch.float32, device=device).unsqueeze(0)

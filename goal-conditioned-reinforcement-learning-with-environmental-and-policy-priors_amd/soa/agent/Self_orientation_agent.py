@@ -48,6 +48,9 @@ class self_orinetation_agent(ppo_predictor):
             m.to(device)
         return self
 
+    def trainable_nets(self):
+        return [self.actor, self.critic, self.agent_position_preditor]
+
     # ------------------------------------------------------------------ acting
     def orient_probs(self, x8, p4, goal):
         """(Py_prob, Px_prob)-style pair of the reference: 7-way distributions of the two position components."""

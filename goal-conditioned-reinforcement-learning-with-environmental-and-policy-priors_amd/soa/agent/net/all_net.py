@@ -48,7 +48,14 @@ def _conv_stack(in_frames):
 
 
 class TINet(nn.Module):
-    """Frame-stack + coordinate encoder shared by actor and critic (512-d feature)."""
+    """Frame-stack + coordinate encoder shared by actor and critic (512-d feature).
+
+    `nhwc` (class switch, set through `use_nhwc`): run the conv stack on channels-last tensors.  MIOpen's MFMA
+    implicit-GEMM kernels are NHWC kernels; fed NCHW tensors it wraps every conv in `batched_transpose` launches
+    (26 % of a PPO update, profiles/r01_ppo_fp32_kernel_stats_top45.csv) and falls back to a non-MFMA Winograd kernel
+    for the stride-2 backward-data convs (another 26 %).  Needs PYTORCH_MIOPEN_SUGGEST_NHWC=1 in the environment
+    BEFORE torch is imported (otherwise PyTorch hands MIOpen NCHW copies of the channels-last tensors)."""
+    nhwc = False
 
     def __init__(self):
         super().__init__()
@@ -61,6 +68,19 @@ class TINet(nn.Module):
         self.upsamplingnearest = nn.UpsamplingNearest2d(scale_factor=4)
         self.apply(reference_init)
 
+    def _convs(self, img):
+        """cnn_base; in channels-last fp32 mode each Conv2d + ReLU pair runs as MIOpen conv + one fused epilogue pass."""
+        if not (self.nhwc and img.is_cuda and img.dtype == torch.float32 and not torch.is_autocast_enabled()):
+            return self.cnn_base(img)
+        from .... import ppo_ops
+        x = img
+        for m in self.cnn_base:
+            if isinstance(m, nn.Conv2d):
+                x = ppo_ops.conv_bias_relu(x, m.weight, m.bias, m.stride)
+            elif not isinstance(m, nn.ReLU):                  # the ReLUs are part of the fused epilogue
+                x = m(x)
+        return x
+
     def widen_input(self, in_frames):
         """Swap the first conv for an `in_frames`-channel one (predictor variants, all_net.py:255,284)."""
         self.cnn_base[0] = nn.Conv2d(in_frames, 64, kernel_size=4, stride=2)
@@ -69,9 +89,33 @@ class TINet(nn.Module):
         B, F, _ = state_matrix.shape
         coords = torch.cat([position.contiguous().view(B, -1), goal], dim=1)
         coords = torch.relu(self.positionnet(coords))
-        img = self.upsamplingnearest(state_matrix.contiguous().view(B, F, GRID, GRID))
-        feat = torch.relu(self.fc0(self.cnn_base(img)))
+        img = state_matrix.contiguous().view(B, F, GRID, GRID)
+        if self.nhwc:
+            img = img.contiguous(memory_format=torch.channels_last)
+        img = self.upsamplingnearest(img)
+        feat = torch.relu(self.fc0(self._convs(img)))
         return torch.relu(self.fc1(torch.cat([feat, coords], dim=1)))
+
+
+def use_nhwc(modules, enable=True):
+    """Switch the conv stacks of the given networks (already on the GPU) to channels-last weights and activations
+    (see TINet.nhwc).  PyTorch reads PYTORCH_MIOPEN_SUGGEST_NHWC once, at the first convolution of the process: it is
+    set here if absent, and a probe conv verifies that MIOpen really receives and returns channels-last tensors."""
+    import os
+    if enable:
+        os.environ.setdefault("PYTORCH_MIOPEN_SUGGEST_NHWC", "1")
+        dev = next(modules[0].parameters()).device if modules else torch.device("cuda", torch.cuda.current_device())
+        if dev.type != "cuda":
+            raise RuntimeError("use_nhwc: move the networks to the GPU first")
+        probe = torch.nn.functional.conv2d(torch.zeros(1, 4, 8, 8, device=dev).contiguous(memory_format=torch.channels_last),
+                                           torch.zeros(4, 4, 3, 3, device=dev).contiguous(memory_format=torch.channels_last))
+        if not probe.is_contiguous(memory_format=torch.channels_last):
+            raise RuntimeError("channels-last convs need PYTORCH_MIOPEN_SUGGEST_NHWC=1 before the process's first convolution")
+    for m in modules:
+        for sub in m.modules():
+            if isinstance(sub, TINet):
+                sub.nhwc = bool(enable)
+                sub.cnn_base.to(memory_format=torch.channels_last if enable else torch.contiguous_format)
 
 
 class _Head(nn.Module):

@@ -29,6 +29,7 @@ class VecPPOTrainer:
         d = self.device = engine.device
         T, N = self.T, self.N
         self.frame_codes = bool(frame_codes)
+        self.reuse_next_values = True             # V(s'_t) = V(s_{t+1}) inside an episode (_values_rollout)
         if self.frame_codes:
             self.frames_buf = torch.zeros((T + 4, N, 304), dtype=torch.uint8, device=d)
         else:
@@ -155,20 +156,34 @@ class VecPPOTrainer:
         """Hook: what the networks get as goal before / after the step, from a sample_goal() record."""
         return goal
 
-    def _values(self, t_idx, n_idx, goal):
-        """critic(s, g) and critic(s', g) of samples (t, n) with per-sample goals, in chunks."""
+    def _values_one(self, t_idx, n_idx, goal, after):
+        """critic(s, g) (after=False) or critic(s', g) (after=True) of samples (t, n) with per-sample goals, in chunks."""
         total = t_idx.numel()
         v = torch.empty(total, device=self.device)
-        nv = torch.empty(total, device=self.device)
         self.agent.critic.eval()
         for i in range(0, total, self.value_chunk):
             sl = slice(i, min(total, i + self.value_chunk))
-            s0, p0 = self._stacks(t_idx[sl], n_idx[sl], after=False)
-            v[sl] = self.agent.critic_value(self.agent.policy_input(s0), p0,
-                                            self.goal_input(goal[sl], False)).view(-1)
-            s1, p1 = self._stacks(t_idx[sl], n_idx[sl], after=True)
-            nv[sl] = self.agent.critic_value(self.agent.policy_input(s1), p1,
-                                             self.goal_input(goal[sl], True)).view(-1)
+            s, p = self._stacks(t_idx[sl], n_idx[sl], after=after)
+            v[sl] = self.agent.critic_value(self.agent.policy_input(s), p, self.goal_input(goal[sl], after)).view(-1)
+        return v
+
+    def _values(self, t_idx, n_idx, goal):
+        """critic(s, g) and critic(s', g) of samples (t, n) with per-sample goals."""
+        return self._values_one(t_idx, n_idx, goal, False), self._values_one(t_idx, n_idx, goal, True)
+
+    def _values_rollout(self, goal, done):
+        """V(s_t) and V(s'_t) of every rollout sample with ONE critic pass over the rollout instead of two: unless the
+        episode ends at t, the state after step t IS the acting state of step t + 1 (same frames, same positions, same
+        goal input), so V(s'_t) = V(s_{t+1}); only done steps and the last row need their own evaluation
+        (the reference evaluates s[:,1:5] and s[:,0:4] separately because its records are independent, PPO.py:112-114)."""
+        T, N = self.T, self.N
+        idx = torch.arange(T * N, device=self.device)
+        t_idx, n_idx = idx // N, idx % N
+        v = self._values_one(t_idx, n_idx, goal, False)
+        nv = torch.empty_like(v)
+        nv.view(T, N)[:-1] = v.view(T, N)[1:]
+        need = torch.nonzero((done.view(-1) != 0) | (t_idx == T - 1)).view(-1)
+        nv[need] = self._values_one(t_idx[need], n_idx[need], goal[need], True)
         return v, nv
 
     @torch.no_grad()
@@ -177,7 +192,8 @@ class VecPPOTrainer:
         total = T * N
         idx = torch.arange(total, device=self.device)
         done = (self.term | self.trunc).contiguous()
-        v, nv = self._values(idx // N, idx % N, self.sample_goal(idx // N, idx % N, self.goal1.expand(total, 2), done.view(-1)))
+        goal = self.sample_goal(idx // N, idx % N, self.goal1.expand(total, 2), done.view(-1))
+        v, nv = self._values_rollout(goal, done) if self.reuse_next_values else self._values(idx // N, idx % N, goal)
         adv, target, ret = ppo_ops.gae(self.reward, v.view(T, N), nv.view(T, N), done, gamma=self.agent.gamma,
                                        lam=self.agent.gae_lambda, use_done_mask=self.agent.use_done_mask)
         critic_target = target if self.agent.gae_lambda == 0.0 else ret

@@ -41,6 +41,9 @@ def build_parser():
     p.add_argument("--updates", type=int, default=1)
     p.add_argument("--amp", default="fp32", choices=["fp32", "bf16"],
                    help="GEMM dtype of the actor-critic (bf16 = torch.autocast, no parity claim; fp32 = reference)")
+    p.add_argument("--conv_layout", default="nhwc", choices=["nhwc", "nchw"],
+                   help="nhwc: channels-last conv stacks + fused bias/ReLU epilogues (fast on MI355X); nchw: the literal "
+                        "nn.Sequential path")
     p.add_argument("--frame_codes", action="store_true", help="store rollout frames as uint8 codes (4x smaller, exact)")
     p.add_argument("--k_epochs", type=int, default=10)
     p.add_argument("--k_epochs_orientation", type=int, default=50, help="SoA: epochs of the orientation head per update")
@@ -86,6 +89,8 @@ def main(argv=None, predictor=False, soa=False):
     agent.sample_seed = (seed or 0) + 7919 * rank
     agent.amp_dtype = torch.bfloat16 if args.amp == "bf16" else None
     agent.to(device)
+    if args.conv_layout == "nhwc":
+        agent.use_nhwc()
     twdist.broadcast_parameters([agent.actor, agent.critic] +
                                 ([agent.encoder, agent.decoder, agent.predictor] if (predictor or soa) else []) +
                                 ([agent.agent_position_preditor] if soa else []))

@@ -105,6 +105,17 @@ int ppo_her_relabel(const float *pos, const uint8_t *terminated, const uint8_t *
                     int N, int max_goals, const int64_t *offsets, int32_t *counts, int32_t *out_t, int32_t *out_n,
                     float *out_goal, float *out_reward, uint8_t *out_done, void *stream);
 
+/* Epilogues of the conv layers of TINet (all_net.py:141-150: Conv2d + ReLU x 4) on channels-last activations
+ * float[n_pixels][C] (n_pixels = B * H * W, C % 4 == 0, C <= 256); the conv GEMMs themselves run in MIOpen.
+ *   ppo_bias_relu_nhwc               y <- relu(y + bias[c])  in place: what Conv2d's bias add + nn.ReLU compute, one pass.
+ *   ppo_relu_bwd_bias_grad_nhwc      gx = gy * (y > 0)  (ReLU backward on the saved OUTPUT y) and the bias gradient as
+ *                                    per-block partial sums partial[blocks][C] (the caller sums them: deterministic);
+ *                                    blocks = ppo_relu_bwd_bias_grad_nhwc_blocks(n_pixels, C). */
+int ppo_bias_relu_nhwc(float *y, const float *bias, int64_t n_pixels, int C, void *stream);
+int ppo_relu_bwd_bias_grad_nhwc_blocks(int64_t n_pixels, int C);
+int ppo_relu_bwd_bias_grad_nhwc(const float *gy, const float *y, float *gx, float *partial, int64_t n_pixels, int C,
+                                void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -192,3 +192,42 @@ def test_update_default_randperm_equals_sampler_stream():
     agent.update(buf, DEV, 0)
     al = np.array([v for _, v in agent.writer.scalars["loss/action_loss_update"]])
     np.testing.assert_allclose(al, g["upd_action_loss"], rtol=0, atol=1e-5)
+
+
+def test_update_matches_reference_losses_channels_last_fused():
+    """The fast layout (channels-last conv stacks, MIOpen conv + fused bias/ReLU epilogue kernels, fused ReLU-backward
+    + bias-gradient) reproduces the reference's 8 logged update losses within the same 1e-5 as the literal path."""
+    from twoarmy_amd.soa.agent.PPO import PPO
+    g = load_ppo_golden()
+    agent = PPO()
+    agent.actor.load_state_dict(det_weights(agent.actor, 1))
+    agent.critic.load_state_dict(det_weights(agent.critic, 2))
+    agent.batch_size, agent.K_epochs = 16, 2
+    agent.to(DEV).use_nhwc()
+    buf = {k: g["buf_" + k] for k in ("s", "a", "p", "g", "r", "d", "a_logp")}
+    agent.update(buf, DEV, 0, permutations=g["upd_perms"])
+    sc = agent.writer.scalars
+    np.testing.assert_allclose([v for _, v in sc["loss/action_loss_update"]], g["upd_action_loss"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose([v for _, v in sc["loss/value_loss_update"]], g["upd_value_loss"], rtol=0, atol=1e-5)
+
+
+def test_conv_epilogue_kernels_vs_torch():
+    """ppo_bias_relu_nhwc / ppo_relu_bwd_bias_grad_nhwc == relu(conv + b) and its autograd gradients (torch, NCHW)."""
+    from twoarmy_amd import ppo_ops
+    from twoarmy_amd.soa.agent.net.all_net import use_nhwc
+    torch.manual_seed(0)
+    for cin, cout, k, hw, B in ((4, 64, 4, 20, 3), (64, 128, 3, 9, 5), (128, 256, 3, 7, 2)):
+        conv = torch.nn.Conv2d(cin, cout, k, stride=2).to(DEV)
+        x = torch.randn(B, cin, hw, hw, device=DEV, requires_grad=True)
+        y_ref = torch.relu(conv(x))
+        gy = torch.randn_like(y_ref)
+        gx_ref, gw_ref, gb_ref = torch.autograd.grad(y_ref, (x, conv.weight, conv.bias), gy)
+        xn = x.detach().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        use_nhwc([])   # sets the env switch / probes
+        wn = conv.weight.detach().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        bn = conv.bias.detach().clone().requires_grad_(True)
+        y = ppo_ops.conv_bias_relu(xn, wn, bn, (2, 2))
+        gx, gw, gb = torch.autograd.grad(y, (xn, wn, bn), gy)
+        assert torch.allclose(y, y_ref, atol=1e-5, rtol=1e-5)
+        assert torch.allclose(gx, gx_ref, atol=1e-4, rtol=1e-4) and torch.allclose(gw, gw_ref, atol=1e-3, rtol=1e-4)
+        assert torch.allclose(gb, gb_ref, atol=1e-4, rtol=1e-5)

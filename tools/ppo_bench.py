@@ -13,6 +13,8 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if "--nhwc" in sys.argv:
+    os.environ["PYTORCH_MIOPEN_SUGGEST_NHWC"] = "1"          # must be set before torch is imported
 import torch  # noqa: E402
 from twoarmy_amd.engine import TwoarmyEngine  # noqa: E402
 from twoarmy_amd.soa.agent.PPO import PPO  # noqa: E402
@@ -30,6 +32,9 @@ ap.add_argument("--variant", type=int, default=6)
 ap.add_argument("--amp", default="fp32", choices=["fp32", "bf16"])
 ap.add_argument("--frame_codes", action="store_true")
 ap.add_argument("--her", action="store_true")
+ap.add_argument("--unfused", action="store_true", help="with --nhwc: plain Conv2d + ReLU modules (A/B of the fused epilogues)")
+ap.add_argument("--no_value_reuse", action="store_true")
+ap.add_argument("--nhwc", action="store_true", help="channels-last conv stack (PYTORCH_MIOPEN_SUGGEST_NHWC=1)")
 a = ap.parse_args()
 
 
@@ -50,7 +55,14 @@ eng = TwoarmyEngine(a.variant, a.envs, 17, seed=9981)
 agent = PPO()
 agent.K_epochs = a.k_epochs
 agent.amp_dtype = torch.bfloat16 if a.amp == "bf16" else None
+if a.nhwc:
+    agent.to(eng.device)
+    agent.use_nhwc()
+    if a.unfused:
+        from twoarmy_amd.soa.agent.net import all_net
+        all_net.TINet._convs = lambda self, img: self.cnn_base(img)
 tr = VecPPOTrainer(agent, eng, rollout_steps=a.T, minibatch=a.minibatch, frame_codes=a.frame_codes)
+tr.reuse_next_values = not a.no_value_reuse
 roll, upd, recs = [], [], []
 for u in range(a.updates + 1):                 # first pass = warm-up (MIOpen find, allocator)
     torch.cuda.synchronize()
@@ -81,5 +93,6 @@ print(json.dumps({"workload": "full PPO, twoarmy-v%d, %d envs x %d steps, miniba
                                  ", code frames" if a.frame_codes else "", ", HER" if a.her else ""),
                   "rollout_s": r, "update_s": w, "env_steps_per_s_rollout": S / r, "env_steps_per_s_loop": S / (r + w),
                   "rollout_TFLOPs": flop_roll / r / 1e12, "update_TFLOPs": flop_upd / w / 1e12,
+                  "nhwc": a.nhwc, "miopen_find_mode": os.environ.get("MIOPEN_FIND_MODE", "default"),
                   "her_records": sum(recs) / len(recs), "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}))
 eng.close()
