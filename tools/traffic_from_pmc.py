@@ -37,8 +37,8 @@ def main():
     fb = 2.0 * statistics.median(fetch) * 1024.0
     wb = statistics.median(write) * 1024.0
     print(json.dumps({
-        "round": 1, "kernel": KERNEL,
-        "config": "bench.py default: v6, 4096 envs, T=128 steps per launch, view 17, native pitched layout",
+        "round": 2, "kernel": KERNEL,
+        "config": "bench.py default: v6, 4096 envs, T=128 steps per launch, view 17, record layout (tw_alloc_outputs)",
         "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and, in a separate pass, --pmc WRITE_SIZE; median over the "
                   "128-step launches; counters are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a "
                   "wide coalesced read stream); WRITE_SIZE as is",
