@@ -57,6 +57,7 @@ _SIGS = {
     "tw_rollout": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "tw_set_envs_per_wave": (C.c_int, [_vp, C.c_int]),
     "tw_set_pipeline": (C.c_int, [_vp, C.c_int]),
+    "tw_fallback_count": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "tw_fill_actions": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "tw_state_ptrs": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "tw_get_state_host": (C.c_int, [_vp, _vp, _vp, _vp]),

@@ -87,6 +87,7 @@ struct Params {
     int *abnormal;            // device flag raised by the pipelined kernel when an env leaves normal play
     int *abnormal_other;      // the flag of the previous pipelined launch: cleared here instead of a memset node
     int only_if_flagged;      // sequential kernel: run only if *abnormal != 0 (fallback launch)
+    int *fb_count;            // engine statistic: pipelined launches that had to be re-run by the fallback launch
     int n_envs;
     int view;
     int variant;
@@ -458,18 +459,13 @@ __device__ unsigned long long g_stamp2[64][16][3];   // per wave: tasks, poll cy
 // Launch bounds: 4 waves per SIMD for E <= 2 (<= 128 VGPRs): at 4096 envs the grid is only 4096 / E
 // single-wave workgroups for 1024 SIMDs, and a lone wave issues a dependent instruction every
 // ~11 cycles, so residency (not instruction count) sets the step time.
+// The whole T-step rollout of E consecutive envs (n0 ..) by ONE wavefront; `lds_env` / `stage` / `recs` / `act_lds` are
+// that wavefront's LDS areas.
 template <int E, int VARIANT, bool FAST>
-__global__ __launch_bounds__(64, (E == 1 ? 4 : 2)) void tw_rollout_kernel(Params p) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds_env[E * ENV_WORDS];
-    __shared__ __attribute__((aligned(16))) uint32_t stage[STAGE_WORDS];
-    __shared__ int32_t recs[E * REC];
-    __shared__ int32_t act_lds[64 * E];
-
+__device__ __forceinline__ void rollout_body(const Params &p, const int n0, const int lane, uint32_t *lds_env,
+                                             uint32_t *stage, int32_t *recs, int32_t *act_lds) {
     constexpr bool V4 = VARIANT == 4;
-    if (p.only_if_flagged && *p.abnormal == 0) return;   // fallback launch behind the pipelined kernel
-    const int lane = threadIdx.x;
     const int N = p.n_envs;
-    const int n0 = blockIdx.x * E;                      // first env of this wave
     const int n_mine = n0 + lane;                       // env of this lane (logic phase)
     const bool active = lane < E && n_mine < N;
     const uint32_t env_id = p.env_id0 + (uint32_t)n_mine;
@@ -989,6 +985,27 @@ __global__ __launch_bounds__(64, (E == 1 ? 4 : 2)) void tw_rollout_kernel(Params
         }
     }
 }
+
+// One wavefront per workgroup; workgroup b owns envs b*E .. b*E+E-1.  The flag-gated fallback launch behind the pipelined
+// kernel uses a SMALL grid and walks the env groups with a grid stride: when the flag is clear (always, in normal play)
+// its cost is one kernel boundary instead of the dispatch of N/E workgroups (6 us -> ~2 us per rollout at 4096 envs).
+template <int E, int VARIANT, bool FAST>
+__global__ __launch_bounds__(64, (E == 1 ? 4 : 2)) void tw_rollout_kernel(Params p) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds_env[E * ENV_WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t stage[STAGE_WORDS];
+    __shared__ int32_t recs[E * REC];
+    __shared__ int32_t act_lds[64 * E];
+    if (p.only_if_flagged) {                             // fallback launch behind the pipelined kernel
+        if (*p.abnormal == 0) return;
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(p.fb_count, 1);
+    }
+    const int groups = (p.n_envs + E - 1) / E;
+    for (int b = blockIdx.x; b < groups; b += gridDim.x) {
+        rollout_body<E, VARIANT, FAST>(p, b * E, threadIdx.x, lds_env, stage, recs, act_lds);
+        wave_sync();
+    }
+}
+
 
 // ---------------------------------------------------------------- the pipelined rollout kernel
 // Normal play only (auto-reset on, Philox draws, native layouts, facing up): in that regime the grid is
@@ -1566,6 +1583,7 @@ struct tw_engine {
     int parity;
     int envs_per_wave;              // 0 = auto
     int pipeline;                   // 1 = use the pipelined kernel when eligible (TW_PIPELINE=0 disables)
+    int *fb_count;                  // device counter: pipelined launches re-run by the sequential fallback
     int slab_backing;               // how tw_alloc_outputs backs its slab (0 hipMalloc, 1 mapped 2 MiB granules, ...)
 };
 
@@ -1595,6 +1613,7 @@ Params base_params(const tw_engine *e) {
     p.type = e->type; p.colour = e->colour; p.rec = e->rec;
     p.type_out = e->type; p.colour_out = e->colour; p.rec_out = e->rec;
     p.abnormal = e->abnormal; p.abnormal_other = e->abnormal + 1; p.only_if_flagged = 0;
+    p.fb_count = e->fb_count;
     p.n_envs = e->n_envs; p.view = e->view; p.variant = e->variant;
     p.seed_lo = (uint32_t)e->seed; p.seed_hi = (uint32_t)(e->seed >> 32);
     p.env_id0 = e->env_id0;
@@ -1626,7 +1645,8 @@ bool params_fast(const tw_engine *e, const Params &p, bool allow_codes) {
 
 template <int E>
 void launch_variant(const tw_engine *e, const Params &p, hipStream_t st) {
-    const int grid = (e->n_envs + E - 1) / E;
+    int grid = (e->n_envs + E - 1) / E;
+    if (p.only_if_flagged && grid > 256) grid = 256;        // grid-stride fallback launch (see tw_rollout_kernel)
     const bool fast = params_fast(e, p, false);
     if (e->variant == 4) {
         if (fast) hipLaunchKernelGGL((tw_rollout_kernel<E, 4, true>), dim3(grid), dim3(64), 0, st, p);
@@ -1719,11 +1739,12 @@ int tw_create(tw_engine **out, int variant, int n_envs, int view_size, int devic
     rr[3] = hipMalloc((void **)&e->type2, (size_t)n_envs * NC);
     rr[4] = hipMalloc((void **)&e->colour2, (size_t)n_envs * NC);
     rr[5] = hipMalloc((void **)&e->rec2, (size_t)n_envs * REC * sizeof(int32_t));
-    rr[6] = hipMalloc((void **)&e->abnormal, 2 * sizeof(int));
+    rr[6] = hipMalloc((void **)&e->abnormal, 3 * sizeof(int));
     for (int i = 0; i < 7; ++i)
         if (rr[i] != hipSuccess) { hipError_t bad = rr[i]; tw_destroy(e); return hip_fail(bad); }
     {
-        hipError_t me = hipMemset(e->abnormal, 0, 2 * sizeof(int));
+        hipError_t me = hipMemset(e->abnormal, 0, 3 * sizeof(int));
+        e->fb_count = e->abnormal + 2;
         if (me != hipSuccess) { tw_destroy(e); return hip_fail(me); }
     }
     {   // the pipelined kernel needs > 64 KB of dynamic LDS
@@ -1756,6 +1777,14 @@ int tw_destroy(tw_engine *e) {
     if (e->rec2) (void)hipFree(e->rec2);
     if (e->abnormal) (void)hipFree(e->abnormal);
     free(e);
+    return TW_OK;
+}
+
+int tw_fallback_count(tw_engine *e, int *count) {
+    if (!e || !count) return TW_E_ARG;
+    DeviceGuard g(e->device);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(count, e->fb_count, sizeof(int), hipMemcpyDeviceToHost));
     return TW_OK;
 }
 
@@ -1868,22 +1897,30 @@ namespace {
 
 struct Slab {
     void *base = nullptr;
-    size_t bytes = 0;
+    size_t bytes = 0, chunk = 0;
     int backing = 0;                                  // 0 hipMalloc, >0 mapped hipMemCreate granules
     std::vector<hipMemGenericAllocationHandle_t> handles;
+    std::vector<size_t> slots;                        // handles[i] is mapped at base + slots[i] * chunk
 };
 std::mutex g_slab_mu;
 std::map<void *, Slab> g_slabs;
 
-void slab_release(Slab &s) {
-    if (!s.base) return;
-    if (s.backing == 0) { (void)hipFree(s.base); }
+int slab_release(Slab &s) {
+    if (!s.base) return TW_OK;
+    hipError_t first = hipSuccess;
+    auto note = [&](hipError_t e) { if (e != hipSuccess && first == hipSuccess) first = e; };
+    if (s.backing == 0) { note(hipFree(s.base)); }
     else {
-        (void)hipMemUnmap(s.base, s.bytes);
-        for (auto h : s.handles) (void)hipMemRelease(h);
-        (void)hipMemAddressFree(s.base, s.bytes);
+        // one unmap per mapping, then the physical chunks go back to the driver.  The ADDRESS RANGE is deliberately kept
+        // reserved (hipMemAddressFree is never called): on ROCm 7.2 a range that was freed and handed out again by a later
+        // hipMemAddressReserve served stale translations -- a rollout into the new slab lost ~10 % of its rows
+        // (tools/dbg_fallback.py; leak / keep-range / free-range: fine / fine / corrupt).  The cost is virtual
+        // address space only (about 1 GiB per released slab of the benchmark size, out of 128 TiB).
+        for (size_t i = 0; i < s.handles.size(); ++i) note(hipMemUnmap((char *)s.base + s.slots[i] * s.chunk, s.chunk));
+        for (auto h : s.handles) note(hipMemRelease(h));
     }
     s.base = nullptr;
+    return first == hipSuccess ? TW_OK : hip_fail(first);
 }
 
 // backing: 0 hipMalloc; k > 0: the slab is a contiguous virtual range backed by separately created physical chunks
@@ -1912,6 +1949,7 @@ int slab_alloc(int device, size_t bytes, int backing, Slab &s) {
     size_t chunk = backing >= 99 ? bytes : ((size_t)2 << 20) << (backing - 1);
     chunk = (chunk + gran - 1) / gran * gran;
     s.bytes = (bytes + chunk - 1) / chunk * chunk;
+    s.chunk = chunk;
     const size_t nchunks = s.bytes / chunk;
     hipError_t err = hipMemAddressReserve(&s.base, s.bytes, gran, nullptr, 0);
     if (err != hipSuccess) { s.base = nullptr; return hip_fail(err); }
@@ -1934,6 +1972,7 @@ int slab_alloc(int device, size_t bytes, int backing, Slab &s) {
         err = hipMemMap((char *)s.base + slot[i] * chunk, chunk, 0, h, 0);
         if (err != hipSuccess) { (void)hipMemRelease(h); break; }
         s.handles.push_back(h);
+        s.slots.push_back(slot[i]);
         is_mapped[slot[i]] = 1;
     }
     if (err == hipSuccess) {
@@ -1947,7 +1986,7 @@ int slab_alloc(int device, size_t bytes, int backing, Slab &s) {
         for (size_t i = 0; i < nchunks; ++i)
             if (is_mapped[i]) (void)hipMemUnmap((char *)s.base + i * chunk, chunk);
         for (auto h : s.handles) (void)hipMemRelease(h);
-        s.handles.clear();
+        s.handles.clear(); s.slots.clear();
         (void)hipMemAddressFree(s.base, s.bytes);
         s.base = nullptr;
         return hip_fail(err);
@@ -2006,10 +2045,10 @@ int tw_free_outputs(tw_outputs *out) {
         s = it->second;
         g_slabs.erase(it);
     }
-    (void)hipDeviceSynchronize();
-    slab_release(s);
+    HIP_TRY(hipDeviceSynchronize());
+    const int rc = slab_release(s);
     memset(out, 0, sizeof(*out));
-    return TW_OK;
+    return rc;
 }
 
 int tw_n_envs(const tw_engine *e) { return e ? e->n_envs : TW_E_ARG; }

@@ -99,7 +99,10 @@ class _OutputSlab:
     def __del__(self):
         try:
             if self.out.slab:
-                _lib.lib().tw_free_outputs(C.byref(self.out))
+                rc = _lib.lib().tw_free_outputs(C.byref(self.out))
+                if rc != 0:
+                    import sys
+                    print("tw_free_outputs failed: rc=%d %s" % (rc, _lib.lib().tw_last_error_message().decode()), file=sys.stderr)
         except Exception:
             pass
 
@@ -149,6 +152,12 @@ class TwoarmyEngine:
 
     def set_pipeline(self, enable):
         _lib.check(_lib.lib().tw_set_pipeline(self._h, int(bool(enable))), "tw_set_pipeline")
+
+    def fallback_count(self):
+        """Pipelined launches re-run by the sequential fallback so far (0 in normal play)."""
+        n = C.c_int()
+        _lib.check(_lib.lib().tw_fallback_count(self._h, C.byref(n)), "tw_fallback_count")
+        return n.value
 
     def set_envs_per_wave(self, e):
         _lib.check(_lib.lib().tw_set_envs_per_wave(self._h, int(e)), "tw_set_envs_per_wave")

@@ -121,6 +121,11 @@ int tw_set_envs_per_wave(tw_engine *e, int envs_per_wave);
  * enable = 0 forces the sequential kernel (also TW_PIPELINE=0). */
 int tw_set_pipeline(tw_engine *e, int enable);
 
+/* Statistic: how many of this engine's pipelined launches so far left normal play (illegal action, injected / drifted
+ * state) and were re-run from their input state by the flag-gated sequential launch behind them.  0 in normal play.
+ * Synchronises the device. */
+int tw_fallback_count(tw_engine *e, int *count);
+
 /* Fill int32[T][N] with the Philox action-slot policy indices the engine would use for its next
  * T steps (t counted from each env's current TW_T). */
 int tw_fill_actions(tw_engine *e, int T, int32_t *actions, void *stream);

@@ -209,6 +209,7 @@ def test_pipelined_equals_sequential_state(variant):
         assert torch.equal(oa[k], ob[k]), k
     for x, y, name in zip(_canon(a.get_state()), _canon(b.get_state()), ("type", "colour", "records")):
         assert np.array_equal(x, y), name
+    assert a.fallback_count() == 0                 # normal play never leaves the pipelined path
 
 
 def _canon(state):
@@ -256,6 +257,7 @@ def test_pipelined_falls_back_on_abnormal_state_and_illegal_actions():
                 assert torch.equal(oa[k], ob[k]), (case, k)
         else:
             assert int(sa[2][:, Fd["ERROR"]].max()) == 1
+        assert a.fallback_count() == 1 and b.fallback_count() == 0, (case, a.fallback_count())   # one launch, re-run once
 
 
 @pytest.mark.parametrize("variant", [6, 4])
