@@ -1062,6 +1062,7 @@ template <bool V4>
 __device__ __forceinline__ bool pipe_state_ok(const EnvS &s) {
     bool ok = normal_mode(s) & ((unsigned)(s.obx[0] - 6) <= 2u) & (s.err == 0) & (s.gx == 14) & (s.gy == 2) &
               (s.max_steps > 0);
+    ok &= s.obx[0] == (int)((0x666787u >> (4 * ((uint32_t)s.step_move % 6u))) & 15u);   // the logic wave's closed form
     if (s.pone) ok &= ((unsigned)(s.wall_i1 - 9) <= 3u) & ((unsigned)(s.wall_i2 - 6) <= 3u);
     if (V4) {
         if (s.patrol) {
@@ -1190,6 +1191,11 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
     }
     const bool policy_idx = (p.flags & TW_F_POLICY_IDX) != 0;
     bool bad = false;
+    // row masks of the two dropped wall blocks and the record bits that only change at a drop / spawn / episode end
+    // (pack_record layout: 17-18 i1-9, 19-20 i2-6, 22 pone, 24 patrol)
+    uint32_t w1 = d.pone ? 0x30u : 0u, w2 = d.pone ? 3u << d.i2 : 0u;
+    uint32_t dynw = d.pone ? (((uint32_t)(d.i1 - 9) & 3u) << 17) | (((uint32_t)(d.i2 - 6) & 3u) << 19) | (1u << 22) : 0u;
+    if (d.patrol) dynw |= 1u << 24;
 
     for (int c0 = 0; c0 < p.T; c0 += PCH) {
         const int len = min(PCH, p.T - c0);
@@ -1212,9 +1218,16 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
             }
             draw_block(p.seed_lo, p.seed_hi, eid, tnow, 1, w);
             packed |= ((w[0] & 1u) << 7) | ((w[1] & 1u) << 8);
-            // action in bits 16..: values outside 0..6 are kept distinguishable (7 = "illegal, was >= 7 -> left", 15 = negative)
-            const uint32_t act_enc = act_in < 0 ? 15u : (act_in > 6 ? 7u : (uint32_t)act_in);
-            drw[i] = packed | (act_enc << 16);
+            // The action is decoded here as well (Env_transact.env_action 4 -> done, twoarmy_v6.py:85-86 ">= 7 -> left",
+            // minigrid.py:1347-1394 move table): bits 16-17 dx + 1, 18-19 dy + 1, bit 20 "the reference raises"
+            // (negative action, env actions 4 / 5: AttributeError) -- the serial chain only adds and tests.
+            int a = act_in;
+            const bool neg = a < 0;
+            if (policy_idx && a == 4) a = 6;
+            if (a >= 7) a = 0;
+            const bool raises = neg || ((0x4Fu >> (a & 7)) & 1u) == 0u;
+            const uint32_t dx1 = raises ? 1u : (0x1558u >> (2 * a)) & 3u, dy1 = raises ? 1u : (0x1585u >> (2 * a)) & 3u;
+            drw[i] = packed | (dx1 << 16) | (dy1 << 18) | ((raises ? 1u : 0u) << 20);
         }
         __syncthreads();
 #ifdef TW_STAMP
@@ -1227,23 +1240,19 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
             // ================= LOGIC: the transition in closed form, one step per iteration
             PSTAMP(pst_t0);
             __builtin_amdgcn_s_setprio(3);        // the serial chain must win issue arbitration on its SIMD
+            uint32_t dr_next = drw[lane < PG ? lane : 0], badw = 0u, last_rec = 0u;
             for (int tl = 0; tl < len; ++tl) {
                 if (lg_active) {
-                    const uint32_t dr = drw[tl * PG + lane];
-                    int action = (int)((dr >> 16) & 15u);
-                    bad |= action == 15;                                  // negative action: AttributeError in the reference
-                    if (policy_idx && action == 4) action = 6;            // Env_transact.env_action
-                    if (action >= 7) action = 0;                          // twoarmy_v6.py:85-86
-                    bad |= ((0x4Fu >> action) & 1u) == 0u;                // env actions 4 / 5 raise
-                    
-                    s.t += 1;
+                    const uint32_t dr = dr_next;
+                    dr_next = drw[min(tl + 1, len - 1) * PG + lane];      // next step's word: its LDS latency leaves the chain
+                    badw |= dr;                                           // bit 20: the reference raises on this action
                     s.step_move += 1;
                     s.m6 = s.m6 == 5 ? 0 : s.m6 + 1;
-                    s.m4 = (s.m4 + 1) & 3;
+                    if (V4) s.m4 = (s.m4 + 1) & 3;
                     const int m6 = s.m6;
-                    d.b0 += (m6 <= 1) ? 1 : (m6 <= 3 ? -1 : 0);          // twoarmy_v6.py:96-112
-                    bad |= (unsigned)(d.b0 - 6) > 2u;
-                    d.b0 = min(max(d.b0, 6), 8);
+                    // row-8 balls (twoarmy_v6.py:96-112): the triple's x is a pure function of step_move % 6
+                    // (7 at reset, +1 for m6 in {0,1}, -1 for {2,3}, 0 for {4,5}); verified against the record at launch
+                    const int b0 = (int)((0x666787u >> (4 * m6)) & 15u);
                     if (V4) {                                             // twoarmy_v4.py:115-176
                         if (s.upd_long) {
                             s.upd_horiz = 0;
@@ -1266,32 +1275,44 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
                         bad |= d.patrol && (((unsigned)(d.o1y0 - 3) > 2u) | ((unsigned)(d.o2x0 - 5) > 5u));
                         d.o1y0 = min(max(d.o1y0, 3), 5); d.o2x0 = min(max(d.o2x0, 5), 10);
                     }
-                    // MiniGridEnv.step (minigrid.py:1333-1441) against the closed-form grid
+                    // MiniGridEnv.step (minigrid.py:1333-1441): is the target cell free?  One bitmask per grid row
+                    // (bit x set = cell (x, ty) blocks): border / row-8 walls + ball triple + dropped 2x2 wall blocks
+                    // (+ patrol column and square).  The goal cell (14, 2) is never blocked.
                     s.step_count += 1;
-                    const int tx = s.ax + (int)((0x1558u >> (2 * action)) & 3u) - 1;
-                    const int ty = s.ay + (int)((0x1585u >> (2 * action)) & 3u) - 1;
-                    const uint32_t ct = analytic_cell(tx, ty, d) & 0xffu;
-                    const bool enter = (ct == 1u) | (ct == 8u);
+                    const int tx = s.ax + (int)((dr >> 16) & 3u) - 1;
+                    const int ty = s.ay + (int)((dr >> 18) & 3u) - 1;
+                    uint32_t rb = ty == 8 ? (0x1F83Fu | (7u << b0)) : 0x10001u;
+                    rb = (unsigned)(ty - 1) > 14u ? 0x1FFFFu : rb;
+                    rb |= (unsigned)(ty - d.i1) <= 1u ? w1 : 0u;
+                    rb |= (unsigned)(ty - 11) <= 1u ? w2 : 0u;
+                    if (V4) {
+                        const uint32_t pm = d.patrol ? ~0u : 0u;
+                        rb |= (unsigned)(ty - d.o1y0) <= 2u ? ((1u << 12) & pm) : 0u;
+                        rb |= (unsigned)(ty - 4) <= 1u ? ((3u << d.o2x0) & pm) : 0u;
+                    }
+                    const bool enter = ((rb >> tx) & 1u) == 0u;
                     s.ax = enter ? tx : s.ax;
                     s.ay = enter ? ty : s.ay;
-                    int terminated = ct == 8u;
+                    int terminated = (tx == 14) & (ty == 2);
                     int truncated = s.step_count >= s.max_steps;
-                    bad |= ((unsigned)(s.ax - 1) > 14u) | ((unsigned)(s.ay - 1) > 14u);
-                    const int pone_pre = d.pone, patrol_pre = d.patrol;
+                    const uint32_t seen = dynw & ((1u << 22) | (1u << 24));   // what gen_obs() saw: pone / patrol before this step's drop / spawn
                     // ---- after gen_obs(): wall drop, patrol spawn (twoarmy_v6.py:182-198, v4:181-225)
                     if (!d.pone && (s.ax > 3 || s.ay < 14)) {
                         d.i1 = V4 ? 9 + (int)((dr >> 1) & 3u) : 11;
                         d.i2 = V4 ? 6 + (int)((dr >> 3) & 3u) : 8;
                         d.pone = 1;
+                        w1 = 0x30u; w2 = 3u << d.i2;
+                        dynw = (dynw & ~(15u << 17)) | ((uint32_t)(d.i1 - 9) << 17) | ((uint32_t)(d.i2 - 6) << 19) | (1u << 22);
                     }
                     if (V4 && !d.patrol && s.ay <= 8) {
                         d.o2x0 = 6 + (int)((dr >> 5) & 3u);
                         d.o1y0 = 4;
                         d.patrol = 1;
+                        dynw |= 1u << 24;
                     }
                     // shaped reward (twoarmy_v6.py:231-294)
                     int reward = R_STEP;
-                    const bool in_span = (unsigned)(s.ax - d.b0) <= 2u;
+                    const bool in_span = (unsigned)(s.ax - b0) <= 2u;
                     bool hit = in_span & (s.ay == 8);
                     reward = hit ? R_HIT : reward;
                     reward = (in_span & (s.ay == 9)) ? R_RISK : reward;
@@ -1310,25 +1331,32 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
                     s.first_room2 = room2 ? 0 : s.first_room2;
                     s.risk += (reward == R_RISK);
                     truncated |= (reward == R_RISK) & (s.risk > 5);
-                    const int rec_ax = s.ax, rec_ay = s.ay;
-                    const Dyn rec_d = d;
+                    if (terminated) reward = R_GOAL;
+                    // record of this env-step (pack_record's layout): assembled from the registers that already hold
+                    // their fields in place; single-word publish, the logic wave issues NO vector-memory op in its loop
+                    uint32_t rec = (uint32_t)s.ax | ((uint32_t)s.ay << 5) | ((uint32_t)(b0 - 6) << 10) | dynw | (seen >> 1) |
+                                   ((uint32_t)reward << 25) | ((uint32_t)terminated << 28) | ((uint32_t)(truncated != 0) << 29) |
+                                   REC_VALID;
+                    if (V4) rec |= ((uint32_t)(d.o1y0 - 3) << 12) | ((uint32_t)(d.o2x0 - 5) << 14);
                     if (terminated || truncated) {                        // twoarmy_v6.py:296-318 + auto-reset
-                        if (terminated) reward = R_GOAL;
                         s.step_move = 0; s.m6 = 0; s.m4 = 0; s.first_room2 = 1; s.risk = 0;
                         const int ca = (dr >> 7) & 1, cb = (dr >> 8) & 1;
                         s.up1 = 1 - ca; s.right2 = ca;
                         s.upd_horiz = 1 - cb; s.upd_long = cb;
                         s.episodes += 1;
-                        d.pone = 0; d.patrol = 0; d.b0 = 7;
+                        d.pone = 0; d.patrol = 0; w1 = 0u; w2 = 0u; dynw = 0u;
                         s.ax = 3; s.ay = 15; s.step_count = 0;
                     }
-                    s.last_reward = reward; s.last_term = terminated; s.last_trunc = truncated;
-                    // single-word publish: valid bit + payload together; the logic wave issues NO vector-memory op in
-                    // its loop (reward / terminated / truncated / pos are written by the emission waves from the record)
-                    ring[tl * PG + lane] = pack_record(rec_ax, rec_ay, rec_d, pone_pre, patrol_pre, reward, terminated,
-                                                       truncated) | REC_VALID;
+                    last_rec = rec;
+                    ring[tl * PG + lane] = rec;
                 }
                 else if (lane < PG) ring[tl * PG + lane] = REC_VALID;   // padding env of a ragged last block
+            }
+            if (lg_active) {                                              // what the loop left for the end of the chunk
+                s.t += (uint32_t)len;                                     // one draw-counter tick per step, whatever happens
+                s.last_reward = (int)((last_rec >> 25) & 7u); s.last_term = (int)((last_rec >> 28) & 1u);
+                s.last_trunc = (int)((last_rec >> 29) & 1u);
+                bad |= ((badw >> 20) & 1u) != 0u;
             }
             if (__ballot(bad) != 0ull && lane == 0) atomicOr(p.abnormal, 1);
             __builtin_amdgcn_s_setprio(0);
@@ -1478,8 +1506,9 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
         r[TW_LAST_REWARD] = s.last_reward; r[TW_LAST_TERM] = s.last_term; r[TW_LAST_TRUNC] = s.last_trunc;
         r[TW_T] = (int32_t)s.t; r[TW_ERROR] = 0;
         r[TW_PONE] = d.pone; r[TW_PATROL] = d.patrol; r[TW_WALL_I1] = d.i1; r[TW_WALL_I2] = d.i2;
+        const int b0_end = (int)((0x666787u >> (4 * s.m6)) & 15u);          // ball triple as a function of step_move % 6
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { r[TW_OBX + k] = d.b0 + k; r[TW_OBY + k] = 8; }
+        for (int k = 0; k < 3; ++k) { r[TW_OBX + k] = b0_end + k; r[TW_OBY + k] = 8; }
         if (V4) {
             r[TW_O1_VALID] = d.patrol; r[TW_O2_VALID] = d.patrol;
             if (d.patrol) {
