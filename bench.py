@@ -365,6 +365,7 @@ def run_ppo_mode(args, rank, world, dev, coll):
         agent.grad_sync = timed_sync if dist.get_backend() == "nccl" else bucket
     eng = TwoarmyEngine(variant, N, 17, device=dev, seed=SEED, env_id0=rank * N)
     tr = VecPPOTrainer(agent, eng, rollout_steps=T, minibatch=args.minibatch, frame_codes=args.matrix_codes)
+    tr.time_phases = True
     roll_s, upd_s, her_n = [], [], []
 
     def iteration(timed):
@@ -411,6 +412,8 @@ def run_ppo_mode(args, rank, world, dev, coll):
                                   "4" if args.predictor else ("3" if world > 1 else "2"), T, args.k_epochs, args.minibatch),
                    "step": "one PPO iteration = %d env-steps + %d optimiser steps" % (S, opt_steps),
                    "envs_per_gpu": N, "rollout_s": r, "update_s": u, "rollout_env_steps_per_s_per_gpu": S / r,
+                   "update_targets_s": tr.last_update_timing["targets_s"], "update_epoch_s": tr.last_update_timing["epoch_s"],
+                   "conv_layout": "nchw (literal nn.Sequential)" if args.nchw else "nhwc + fused upsample/conv1 and conv epilogues",
                    "her_records_per_iteration": sum(her_n) / max(1, len(her_n)),
                    "parallelism": "env-sharded x%d, one gradient-bucket all-reduce per optimiser step" % world,
                    "collective": coll,

@@ -114,6 +114,56 @@ __global__ __launch_bounds__(256) void ppo_relu_bwd_bias_grad_kernel(const float
     }
 }
 
+// ------------------------------------------------------------------ conv1 of TINet, fused with its input upsampling
+// all_net.py:146,176-186: frames (B, F, 17, 17) -> UpsamplingNearest2d(x4) -> Conv2d(F -> 64, k4, s2) -> ReLU = (B, 64, 33, 33).
+// Output row oy reads upsampled rows 2oy .. 2oy+3, i.e. source row m = oy >> 1 for all four taps when oy is even and
+// source rows m, m+1 (two taps each) when oy is odd; the same for columns.  So the layer is a 2x2-tap convolution
+// of the 17x17 frame whose weights depend on the output's (row, column) parity -- 16x fewer input bytes, no 68x68
+// tensor, and the bias add and ReLU happen before the one and only store of the layer's (largest) activation.
+// Folded weights wf[py][px][ty][tx][c][64] (taps that a parity does not have carry zeros) come from the caller.
+// Block = 256 threads = 16 channel quads x 16 pixel slots, one sample per block; per parity phase the thread keeps its
+// 4 taps x F x float4 weights in registers and walks the phase's pixels; x values are LDS broadcasts.
+template <int F>
+__global__ __launch_bounds__(256) void ppo_conv1_up4_kernel(const float *__restrict__ frames, const float4 *__restrict__ wf,
+                                                            const float4 *__restrict__ bias, float4 *__restrict__ out, int B) {
+    __shared__ float xs[F * 18 * 18];                  // [c][18][18]: row / column 17 = zero pad for the (unused) far taps
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int cq = tid & 15, slot = tid >> 4;
+    const float *src = frames + (size_t)b * F * 289;
+    for (int i = tid; i < F * 324; i += 256) {
+        const int c = i / 324, r = i - c * 324, y = r / 18, x = r - y * 18;
+        xs[i] = (y < 17 && x < 17) ? src[c * 289 + y * 17 + x] : 0.f;
+    }
+    __syncthreads();
+    const float4 bv = bias[cq];
+    float4 *dst = out + (size_t)b * 1089 * 16;
+#pragma unroll 1
+    for (int ph = 0; ph < 4; ++ph) {
+        const int py = ph >> 1, px = ph & 1;
+        float4 w[4 * F];
+#pragma unroll
+        for (int k = 0; k < 4 * F; ++k) w[k] = wf[(ph * 4 * F + k) * 16 + cq];      // [ty][tx][c] -> k = (ty*2+tx)*F + c
+        const int ny = 17 - py, nx = 17 - px;               // output rows / columns of this parity
+        for (int q = slot; q < ny * nx; q += 16) {
+            const int m = q / nx, n = q - m * nx;
+            float4 acc = bv;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int ty = t >> 1, tx = t & 1;
+#pragma unroll
+                for (int c = 0; c < F; ++c) {
+                    const float xv = xs[c * 324 + (m + ty) * 18 + n + tx];
+                    const float4 ww = w[t * F + c];
+                    acc.x = fmaf(xv, ww.x, acc.x); acc.y = fmaf(xv, ww.y, acc.y);
+                    acc.z = fmaf(xv, ww.z, acc.z); acc.w = fmaf(xv, ww.w, acc.w);
+                }
+            }
+            acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+            dst[((2 * m + py) * 33 + 2 * n + px) * 16 + cq] = acc;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ GAE: segmented reverse scan
 // Block = 256 threads = 4 waves, GN envs (columns) x chunks of 64 time steps walked from T backwards (GN = 16 for
 // N < 16384 so that a 4096-env rollout still fills 256 workgroups; 64 otherwise).
@@ -565,6 +615,23 @@ int ppo_relu_bwd_bias_grad_nhwc(const float *gy, const float *y, float *gx, floa
     hipLaunchKernelGGL(ppo_relu_bwd_bias_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const float4 *>(gy), reinterpret_cast<const float4 *>(y),
                        reinterpret_cast<float4 *>(gx), reinterpret_cast<float4 *>(partial), (size_t)n_pixels, C / 4, ppb);
+    return check_launch();
+}
+
+int ppo_conv1_up4_bias_relu(const float *frames, int B, int F, const float *folded_w, const float *bias, float *out,
+                            void *stream) {
+    if (!frames || !folded_w || !bias || !out || B <= 0 || ((uintptr_t)out & 15u) || ((uintptr_t)folded_w & 15u) ||
+        ((uintptr_t)bias & 15u))
+        return TW_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (F == 4)
+        hipLaunchKernelGGL(ppo_conv1_up4_kernel<4>, dim3(B), dim3(256), 0, st, frames, reinterpret_cast<const float4 *>(folded_w),
+                           reinterpret_cast<const float4 *>(bias), reinterpret_cast<float4 *>(out), B);
+    else if (F == 8)
+        hipLaunchKernelGGL(ppo_conv1_up4_kernel<8>, dim3(B), dim3(256), 0, st, frames, reinterpret_cast<const float4 *>(folded_w),
+                           reinterpret_cast<const float4 *>(bias), reinterpret_cast<float4 *>(out), B);
+    else
+        return TW_E_ARG;
     return check_launch();
 }
 

@@ -173,3 +173,60 @@ def conv_bias_relu(x, weight, bias, stride):
     """relu(conv2d(x, weight, bias, stride)) for channels-last fp32 device tensors (see _ConvBiasReLU)."""
     assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
     return _ConvBiasReLU.apply(x, weight, bias, tuple(stride))
+
+
+def fold_conv1_weights(w):
+    """Conv2d(F -> 64, k4, s2) weights [64, F, 4, 4] applied to a nearest-x4 upsampled image == parity-dependent 2x2-tap
+    weights on the source image (include/twoarmy_ppo.h): -> float[2][2][2][2][F][64], contiguous."""
+    O, F = w.shape[0], w.shape[1]
+    w = w.detach().reshape(O, F, 4, 4).float()
+    z = torch.zeros_like(w[:, :, 0:1, :])
+    rows = torch.stack([torch.cat([w.sum(2, keepdim=True), z], 2),                       # parity 0: all four rows on tap 0
+                        torch.cat([w[:, :, 0:2].sum(2, keepdim=True), w[:, :, 2:4].sum(2, keepdim=True)], 2)], 0)  # [py][O][F][ty][4]
+    zc = torch.zeros_like(rows[..., 0:1])
+    cols = torch.stack([torch.cat([rows.sum(-1, keepdim=True), zc], -1),
+                        torch.cat([rows[..., 0:2].sum(-1, keepdim=True), rows[..., 2:4].sum(-1, keepdim=True)], -1)], 1)
+    # cols: [py][px][O][F][ty][tx] -> [py][px][ty][tx][F][O]
+    return cols.permute(0, 1, 4, 5, 3, 2).contiguous()
+
+
+class _Conv1Up4(torch.autograd.Function):
+    """relu(conv1(upsample_x4(frames)) + b) in one kernel (ppo_conv1_up4_bias_relu); backward = ReLU mask + bias
+    gradient (ppo_relu_bwd_bias_grad_nhwc) and MIOpen's weight-gradient conv on the upsampled frames, which are only
+    materialised there (the frames themselves need no gradient)."""
+
+    @staticmethod
+    def forward(ctx, frames, w, b):
+        B, F, _ = frames.shape
+        y = torch.empty((B, w.shape[0], 33, 33), dtype=torch.float32, device=frames.device,
+                        memory_format=torch.channels_last)
+        wf = fold_conv1_weights(w)
+        fr = frames.contiguous()
+        _lib.check(_lib.lib().ppo_conv1_up4_bias_relu(_p(fr, torch.float32), B, F, _p(wf), _p(b.detach().contiguous()),
+                                                      C.c_void_p(y.data_ptr()), _stream(y)), "ppo_conv1_up4_bias_relu")
+        ctx.save_for_backward(fr, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        fr, w, y = ctx.saved_tensors
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        B, Cc, H, W = y.shape
+        npix = B * H * W
+        blocks = _lib.lib().ppo_relu_bwd_bias_grad_nhwc_blocks(npix, Cc)
+        g = torch.empty_like(y)
+        partial = torch.empty((blocks, Cc), dtype=torch.float32, device=y.device)
+        _lib.check(_lib.lib().ppo_relu_bwd_bias_grad_nhwc(C.c_void_p(gy.data_ptr()), C.c_void_p(y.data_ptr()),
+                                                          C.c_void_p(g.data_ptr()), _p(partial), npix, Cc, _stream(y)),
+                   "ppo_relu_bwd_bias_grad_nhwc")
+        x_up = torch.nn.functional.interpolate(fr.view(B, -1, 17, 17).contiguous(memory_format=torch.channels_last),
+                                               scale_factor=4, mode="nearest")
+        _, gw, _ = torch.ops.aten.convolution_backward(g, x_up, w, None, [2, 2], [0, 0], [1, 1], False, [0, 0], 1,
+                                                       [False, True, False])
+        return None, gw, partial.sum(0)
+
+
+def conv1_up4_bias_relu(frames, weight, bias):
+    """frames [B, F, 289] (F = 4 or 8) -> relu(conv2d(upsample_x4(frames), weight, bias, stride 2)), channels-last."""
+    assert frames.is_cuda and frames.dtype == torch.float32 and weight.shape[2:] == (4, 4) and weight.shape[0] == 64
+    return _Conv1Up4.apply(frames, weight, bias)

@@ -68,13 +68,16 @@ class TINet(nn.Module):
         self.upsamplingnearest = nn.UpsamplingNearest2d(scale_factor=4)
         self.apply(reference_init)
 
-    def _convs(self, img):
-        """cnn_base; in channels-last fp32 mode each Conv2d + ReLU pair runs as MIOpen conv + one fused epilogue pass."""
+    def _convs(self, img, skip_first=False):
+        """cnn_base; in channels-last fp32 mode each Conv2d + ReLU pair runs as MIOpen conv + one fused epilogue pass
+        (skip_first: `img` already is the first layer's activation)."""
         if not (self.nhwc and img.is_cuda and img.dtype == torch.float32 and not torch.is_autocast_enabled()):
             return self.cnn_base(img)
         from .... import ppo_ops
         x = img
-        for m in self.cnn_base:
+        for k, m in enumerate(self.cnn_base):
+            if skip_first and k < 2:
+                continue
             if isinstance(m, nn.Conv2d):
                 x = ppo_ops.conv_bias_relu(x, m.weight, m.bias, m.stride)
             elif not isinstance(m, nn.ReLU):                  # the ReLUs are part of the fused epilogue
@@ -89,11 +92,20 @@ class TINet(nn.Module):
         B, F, _ = state_matrix.shape
         coords = torch.cat([position.contiguous().view(B, -1), goal], dim=1)
         coords = torch.relu(self.positionnet(coords))
-        img = state_matrix.contiguous().view(B, F, GRID, GRID)
-        if self.nhwc:
-            img = img.contiguous(memory_format=torch.channels_last)
-        img = self.upsamplingnearest(img)
-        feat = torch.relu(self.fc0(self._convs(img)))
+        fused = self.nhwc and state_matrix.is_cuda and state_matrix.dtype == torch.float32 and \
+            not torch.is_autocast_enabled() and F in (4, 8)
+        if fused:
+            # upsample + conv1 + bias + ReLU in one kernel, then MIOpen convs with fused epilogues
+            from .... import ppo_ops
+            c1 = self.cnn_base[0]
+            x = ppo_ops.conv1_up4_bias_relu(state_matrix, c1.weight, c1.bias)
+            feat = torch.relu(self.fc0(self._convs(x, skip_first=True)))
+        else:
+            img = state_matrix.contiguous().view(B, F, GRID, GRID)
+            if self.nhwc:
+                img = img.contiguous(memory_format=torch.channels_last)
+            img = self.upsamplingnearest(img)
+            feat = torch.relu(self.fc0(self._convs(img)))
         return torch.relu(self.fc1(torch.cat([feat, coords], dim=1)))
 
 

@@ -7,6 +7,7 @@ reset).  The 4-frame policy input of any (t, n) is assembled on the fly by ppo_g
 repeats the reset frame at episode starts exactly like np.tile in Env_transact.reset.
 """
 import collections
+import time
 
 import torch
 
@@ -30,6 +31,8 @@ class VecPPOTrainer:
         T, N = self.T, self.N
         self.frame_codes = bool(frame_codes)
         self.reuse_next_values = True             # V(s'_t) = V(s_{t+1}) inside an episode (_values_rollout)
+        self.time_phases = False                  # update(): wall time of target computation vs epochs (one extra sync)
+        self.last_update_timing = None
         if self.frame_codes:
             self.frames_buf = torch.zeros((T + 4, N, 304), dtype=torch.uint8, device=d)
         else:
@@ -215,7 +218,11 @@ class VecPPOTrainer:
     def update(self, permutations=None):
         ag = self.agent
         T, N = self.T, self.N
+        t_begin = time.perf_counter() if self.time_phases else 0.0
         adv, target = self.compute_targets()
+        if self.time_phases:
+            torch.cuda.synchronize(self.device)
+            t_targets = time.perf_counter()
         total = adv.numel()                                           # rollout samples + relabelled records
         base = torch.arange(T * N, device=self.device)
         smp_t, smp_n = (base // N).int(), (base % N).int()
@@ -252,6 +259,11 @@ class VecPPOTrainer:
             assert done_steps == n_steps or not synced, (done_steps, n_steps)
         if ag.use_lr_decay:
             ag.scheduler_actor.step(); ag.scheduler_critic.step()
+        if self.time_phases:
+            torch.cuda.synchronize(self.device)
+            t_end = time.perf_counter()
+            self.last_update_timing = {"targets_s": t_targets - t_begin, "epochs_s": t_end - t_targets,
+                                       "epoch_s": (t_end - t_targets) / max(1, ag.K_epochs), "samples": int(total)}
         self.her = None
         return la, lv
 

@@ -116,6 +116,15 @@ int ppo_relu_bwd_bias_grad_nhwc_blocks(int64_t n_pixels, int C);
 int ppo_relu_bwd_bias_grad_nhwc(const float *gy, const float *y, float *gx, float *partial, int64_t n_pixels, int C,
                                 void *stream);
 
+/* First layer of TINet fused with its input upsampling (all_net.py:146,176-186):
+ *   out = relu(conv2d(upsample_nearest_x4(frames), W, bias, stride 2))       frames float[B][F][17*17], F = 4 or 8
+ * evaluated on the 17x17 frames with parity-folded 2x2-tap weights
+ *   folded_w float[2][2][2][2][F][64] = [row parity][column parity][row tap][column tap][in channel][out channel]
+ * (row parity 0: tap 0 = W rows 0+1+2+3, tap 1 = 0; parity 1: tap 0 = rows 0+1, tap 1 = rows 2+3; columns alike),
+ * out float[B][33][33][64] (channels-last).  Same value as the literal layer up to the summation order. */
+int ppo_conv1_up4_bias_relu(const float *frames, int B, int F, const float *folded_w, const float *bias, float *out,
+                            void *stream);
+
 #ifdef __cplusplus
 }
 #endif

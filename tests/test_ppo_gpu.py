@@ -231,3 +231,27 @@ def test_conv_epilogue_kernels_vs_torch():
         assert torch.allclose(y, y_ref, atol=1e-5, rtol=1e-5)
         assert torch.allclose(gx, gx_ref, atol=1e-4, rtol=1e-4) and torch.allclose(gw, gw_ref, atol=1e-3, rtol=1e-4)
         assert torch.allclose(gb, gb_ref, atol=1e-4, rtol=1e-5)
+
+
+@pytest.mark.parametrize("F", [4, 8])
+def test_fused_upsample_conv1_vs_torch(F):
+    """ppo_conv1_up4_bias_relu (nearest-x4 upsample folded into conv1, + bias + ReLU) == the literal three modules of
+    all_net.py:146,176-186 within fp32 summation-order tolerance, forward and weight / bias gradients."""
+    from twoarmy_amd import ppo_ops
+    from twoarmy_amd.soa.agent.net.all_net import use_nhwc
+    use_nhwc([])
+    torch.manual_seed(F)
+    B = 37
+    conv = torch.nn.Conv2d(F, 64, 4, stride=2).to(DEV)
+    frames = torch.tensor([0.9, -0.9, -0.5, 0.3], device=DEV)[torch.randint(0, 4, (B, F, 289), device=DEV)]
+    ref = torch.relu(conv(torch.nn.functional.interpolate(frames.view(B, F, 17, 17), scale_factor=4, mode="nearest")))
+    gy = torch.randn_like(ref)
+    gw_ref, gb_ref = torch.autograd.grad(ref, (conv.weight, conv.bias), gy)
+    w = conv.weight.detach().clone().requires_grad_(True)
+    b = conv.bias.detach().clone().requires_grad_(True)
+    y = ppo_ops.conv1_up4_bias_relu(frames, w, b)
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    assert torch.allclose(y, ref, atol=2e-5, rtol=1e-5)
+    gw, gb = torch.autograd.grad(y, (w, b), gy)
+    # the ReLU mask may differ where |pre-activation| < 1e-5 (summation order); none of these random cases is that close
+    assert torch.allclose(gw, gw_ref, atol=2e-3, rtol=1e-4) and torch.allclose(gb, gb_ref, atol=1e-3, rtol=1e-5)

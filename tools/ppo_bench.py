@@ -63,6 +63,7 @@ if a.nhwc:
         all_net.TINet._convs = lambda self, img: self.cnn_base(img)
 tr = VecPPOTrainer(agent, eng, rollout_steps=a.T, minibatch=a.minibatch, frame_codes=a.frame_codes)
 tr.reuse_next_values = not a.no_value_reuse
+tr.time_phases = True
 roll, upd, recs = [], [], []
 for u in range(a.updates + 1):                 # first pass = warm-up (MIOpen find, allocator)
     torch.cuda.synchronize()
@@ -93,6 +94,7 @@ print(json.dumps({"workload": "full PPO, twoarmy-v%d, %d envs x %d steps, miniba
                                  ", code frames" if a.frame_codes else "", ", HER" if a.her else ""),
                   "rollout_s": r, "update_s": w, "env_steps_per_s_rollout": S / r, "env_steps_per_s_loop": S / (r + w),
                   "rollout_TFLOPs": flop_roll / r / 1e12, "update_TFLOPs": flop_upd / w / 1e12,
+                  "update_targets_s": tr.last_update_timing["targets_s"], "update_epoch_s": tr.last_update_timing["epoch_s"],
                   "nhwc": a.nhwc, "miopen_find_mode": os.environ.get("MIOPEN_FIND_MODE", "default"),
                   "her_records": sum(recs) / len(recs), "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}))
 eng.close()
