@@ -165,6 +165,128 @@ __global__ __launch_bounds__(64) void mg_gen_obs_kernel(const uint8_t *__restric
     }
 }
 
+// Compile-time view sizes: lane = (env slot e, view column i) -- the same layout the ballot masks of process_vis use --
+// and the lane keeps its whole column (V cells) in registers: no cell goes through LDS, no per-element div / mod.
+// A wave can serve G groups of E = 64 / V envs with the loads of all groups issued before any is used (G times the
+// bytes in flight per wave); measured on 262 144 random 17x17 worlds G = 4 / 2 is 25-35 % SLOWER than G = 1 (89 vs 66 us
+// at V = 7), so G = 1 ships.  Also measured and rejected: staging each (env, plane) span through LDS with 16-byte
+// loads (89 vs 66 us).  V = 7 costs 66 us with or without process_vis; V = 17 went 397 -> 322 us with this kernel.
+template <int V, int G>
+__global__ __launch_bounds__(64) void mg_gen_obs_cols_kernel(const uint8_t *__restrict__ type, const uint8_t *__restrict__ colour,
+                                                             const uint8_t *__restrict__ state, int N, int W, int H,
+                                                             const int32_t *__restrict__ agent_x,
+                                                             const int32_t *__restrict__ agent_y,
+                                                             const int32_t *__restrict__ agent_dir,
+                                                             const uint8_t *__restrict__ carrying, int see_through,
+                                                             uint8_t *__restrict__ image, int image_pitch,
+                                                             uint8_t *__restrict__ vis_mask) {
+    constexpr int E = 64 / V, VV = V * V, EV = E * V, nb = VV * 3, nbp = (nb + 6) & ~3, half = V / 2;
+    __shared__ __attribute__((aligned(4))) uint8_t stage[G * E * nbp];
+    __shared__ int32_t phase[G * E];
+    const int lane = threadIdx.x;
+    const int le = lane / V, li = lane - le * V, i = li;
+    const size_t pitch = image_pitch ? (size_t)image_pitch : (size_t)nb;
+    const int nbase = blockIdx.x * (E * G);
+    bool act[G];
+    int n[G], ax[G], ay[G], dir[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int ng = nbase + g * E + le;
+        act[g] = lane < EV && ng < N;
+        n[g] = act[g] ? ng : nbase;
+        ax[g] = agent_x[n[g]]; ay[g] = agent_y[n[g]]; dir[g] = agent_dir[n[g]] & 3;
+    }
+    uint32_t cell[G][V], carried[G];
+    int ph[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        // get_view_exts (minigrid.py:1262-1293) and the number of rotate_left applications
+        const int topx = dir[g] == 0 ? ax[g] : (dir[g] == 2 ? ax[g] - V + 1 : ax[g] - half);
+        const int topy = dir[g] == 1 ? ay[g] : (dir[g] == 3 ? ay[g] - V + 1 : ay[g] - half);
+        const int k = (dir[g] + 1) & 3;
+        // view (i, j) <- slice (si, sj): rotate_left maps old (a, b) -> new (b, V-1-a), inverted k times.  For this lane i
+        // is fixed, so (x, y) walks a straight line in the world as j grows: start + j * step.
+        const int sx0 = k == 0 ? i : (k == 1 ? V - 1 : (k == 2 ? V - 1 - i : 0));
+        const int sy0 = k == 0 ? 0 : (k == 1 ? i : (k == 2 ? V - 1 : V - 1 - i));
+        const int dxj = k == 1 ? -1 : (k == 3 ? 1 : 0), dyj = k == 0 ? 1 : (k == 2 ? -1 : 0);
+        const size_t pbase = (size_t)n[g] * W * H;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const int x = topx + sx0 + j * dxj, y = topy + sy0 + j * dyj;
+            uint32_t c = WALL_CELL;                                         // Grid.slice: outside the world -> Wall()
+            if (act[g] && x >= 0 && x < W && y >= 0 && y < H) {
+                const size_t o = pbase + (size_t)y * W + x;
+                const uint32_t t = type[o];
+                c = (t <= T_EMPTY) ? EMPTY_CELL : (t | ((uint32_t)colour[o] << 8) | ((state ? (uint32_t)state[o] : 0u) << 16));
+            }
+            cell[g][j] = c;
+        }
+        carried[g] = EMPTY_CELL;
+        if (carrying && carrying[(size_t)n[g] * 3] != 0)
+            carried[g] = carrying[(size_t)n[g] * 3] | ((uint32_t)carrying[(size_t)n[g] * 3 + 1] << 8) |
+                         ((uint32_t)carrying[(size_t)n[g] * 3 + 2] << 16);
+        ph[g] = (int)((uintptr_t)(image + (size_t)n[g] * pitch) & 3u);
+        if (act[g] && li == 0) phase[g * E + le] = ph[g];
+    }
+    constexpr uint64_t all = EV >= 64 ? ~0ull : ((1ull << EV) - 1ull);
+    uint64_t seg_first = 0, seed0 = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) { seg_first |= 1ull << (e * V); seed0 |= 1ull << (e * V + half); }   // mask[V//2, V-1] = True
+    const uint64_t seg_last = seg_first << (V - 1);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        // ---- process_vis (minigrid.py:795-832): rows from the agent's row (V-1) upwards, all envs of the group at once
+        uint32_t vis = 0;                                                   // bit j: cell (i, j) of this lane's env is visible
+        if (see_through) {
+            vis = (1u << V) - 1u;
+        } else {
+            uint64_t seed = seed0;
+#pragma unroll
+            for (int j = V - 1; j >= 0; --j) {
+                const uint64_t p = __ballot(act[g] && see_behind(cell[g][j]));
+                const uint64_t r = flood_right(seed, (p << 1) & ~seg_first & all);     // first sweep: i = 0 .. V-2
+                const uint64_t tl = r & p & ~seg_last;
+                const uint64_t r2 = flood_left(r, (p >> 1) & ~seg_last);               // second sweep: i = V-1 .. 1
+                const uint64_t tr = r2 & p & ~seg_first;
+                vis |= (uint32_t)((r2 >> lane) & 1ull) << j;
+                seed = tl | (tl << 1) | tr | (tr >> 1);                                // mask[i +- 1, j-1] and mask[i, j-1]
+            }
+        }
+        // ---- encode (minigrid.py:749-772) into output order [i][j][3]; the agent's cell shows the carried object
+        if (act[g]) {
+            uint8_t *sp = stage + (g * E + le) * nbp + ph[g] + i * V * 3;
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                uint32_t c = cell[g][j];
+                if (i == half && j == V - 1) c = carried[g];                // grid.set(*agent_pos, carrying or None)
+                if (!((vis >> j) & 1u)) c = 0u;
+                sp[3 * j] = (uint8_t)c; sp[3 * j + 1] = (uint8_t)(c >> 8); sp[3 * j + 2] = (uint8_t)(c >> 16);
+            }
+            if (vis_mask) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) vis_mask[(size_t)n[g] * VV + i * V + j] = (uint8_t)((vis >> j) & 1u);
+            }
+        }
+    }
+    wsync();
+    // ---- copy out: per env, the 4-byte aligned slots that overlap its image; whole slots leave as dwords
+    constexpr int slots = (nb + 3) / 4 + 1;
+    const int ne = N - nbase < E * G ? N - nbase : E * G;                   // envs of this wavefront (slot s = g * E + e)
+    for (int idx = lane; idx < ne * slots; idx += 64) {
+        const int sl = idx / slots, d = idx - sl * slots;
+        uint8_t *dst = image + (size_t)(nbase + sl) * pitch;
+        const int b0 = 4 * d - phase[sl];                                   // first image byte of this slot (may be < 0)
+        const uint8_t *sq = stage + sl * nbp + phase[sl];
+        if (b0 >= 0 && b0 + 3 < nb) {
+            *reinterpret_cast<uint32_t *>(dst + b0) = *reinterpret_cast<const uint32_t *>(sq + b0);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (b0 + q >= 0 && b0 + q < nb) dst[b0 + q] = sq[b0 + q];
+        }
+    }
+}
+
 // _reward() = 1 - 0.9 * (step_count / max_steps) as Python evaluates it: three separately rounded double operations.
 // (__dmul_rn / __dsub_rn are plain operators in HIP and would still be contracted into one fma.)
 __device__ __forceinline__ double reference_reward(int step_count, int max_steps) {
@@ -232,17 +354,26 @@ extern "C" int mg_gen_obs(const uint8_t *type, const uint8_t *colour, const uint
     hipLaunchKernelGGL(mg_gen_obs_kernel<VT>, grid, block, lds, (hipStream_t)stream, type, colour, state, n_envs, width, \
                        height, agent_x, agent_y, agent_dir, carrying, view_size, see_through_walls ? 1 : 0, image,      \
                        image_pitch, vis_mask)
-    switch (view_size) {                    // the usual odd sizes get compile-time index arithmetic
-    case 3: MG_LAUNCH(3); break;
-    case 5: MG_LAUNCH(5); break;
-    case 7: MG_LAUNCH(7); break;
-    case 9: MG_LAUNCH(9); break;
-    case 11: MG_LAUNCH(11); break;
-    case 13: MG_LAUNCH(13); break;
-    case 15: MG_LAUNCH(15); break;
-    case 17: MG_LAUNCH(17); break;
+#define MG_LAUNCH_COLS(VT)                                                                                             \
+    do {                                                                                                               \
+        constexpr int GG = 1;   /* env groups per wavefront; 4 (V <= 9) / 2 measured 25-35 % slower: registers, occupancy */ \
+        const dim3 grid_g((n_envs + E * GG - 1) / (E * GG));                                                           \
+        hipLaunchKernelGGL((mg_gen_obs_cols_kernel<VT, GG>), grid_g, block, 0, (hipStream_t)stream, type, colour,      \
+                           state, n_envs, width, height, agent_x, agent_y, agent_dir, carrying,                        \
+                           see_through_walls ? 1 : 0, image, image_pitch, vis_mask);                                   \
+    } while (0)
+    switch (view_size) {                    // the usual odd sizes: lane-per-column kernel with the column in registers
+    case 3: MG_LAUNCH_COLS(3); break;
+    case 5: MG_LAUNCH_COLS(5); break;
+    case 7: MG_LAUNCH_COLS(7); break;
+    case 9: MG_LAUNCH_COLS(9); break;
+    case 11: MG_LAUNCH_COLS(11); break;
+    case 13: MG_LAUNCH_COLS(13); break;
+    case 15: MG_LAUNCH_COLS(15); break;
+    case 17: MG_LAUNCH_COLS(17); break;
     default: MG_LAUNCH(0); break;
     }
+#undef MG_LAUNCH_COLS
 #undef MG_LAUNCH
     return hipGetLastError() == hipSuccess ? TW_OK : TW_E_HIP;
 }
