@@ -278,13 +278,19 @@ template <int A>
 __global__ __launch_bounds__(256) void ppo_loss_kernel(const float *__restrict__ probs, const int32_t *__restrict__ action,
                                                        const float *__restrict__ old_logp, const float *__restrict__ adv,
                                                        const float *__restrict__ value, const float *__restrict__ target_v,
-                                                       int B, float clip, float ent_coef, float *__restrict__ grad_probs,
-                                                       float *__restrict__ grad_value, float *__restrict__ ws) {
+                                                       int B, int n_valid, float clip, float ent_coef,
+                                                       float *__restrict__ grad_probs, float *__restrict__ grad_value,
+                                                       float *__restrict__ ws) {
     __shared__ float sa[256], sv[256];
     const int b = blockIdx.x * 256 + threadIdx.x;
     float la = 0.f, lv = 0.f;
-    if (b < B) {
-        const float invB = 1.0f / (float)B;
+    if (b >= n_valid && b < B) {                      // padding rows of a fixed-shape minibatch: no loss, no gradient
+#pragma unroll
+        for (int k = 0; k < A; ++k) grad_probs[(size_t)b * A + k] = 0.f;
+        grad_value[b] = 0.f;
+    }
+    if (b < n_valid) {
+        const float invB = 1.0f / (float)n_valid;
         float p[A], q[A], l[A];
         bool inside[A];
         float S = 0.f;
@@ -538,14 +544,22 @@ int ppo_adv_norm(float *adv, int64_t n, float eps, double *workspace, void *stre
 int ppo_loss_fwd_bwd(const float *probs, const int32_t *action, const float *old_logp, const float *adv,
                      const float *value, const float *target_v, int B, int A, float clip, float ent_coef,
                      float *losses, float *grad_probs, float *grad_value, float *workspace, void *stream) {
+    return ppo_loss_fwd_bwd_masked(probs, action, old_logp, adv, value, target_v, B, B, A, clip, ent_coef, losses,
+                                   grad_probs, grad_value, workspace, stream);
+}
+
+int ppo_loss_fwd_bwd_masked(const float *probs, const int32_t *action, const float *old_logp, const float *adv,
+                            const float *value, const float *target_v, int B, int n_valid, int A, float clip,
+                            float ent_coef, float *losses, float *grad_probs, float *grad_value, float *workspace,
+                            void *stream) {
     if (!probs || !action || !old_logp || !adv || !value || !target_v || !losses || !grad_probs || !grad_value ||
-        !workspace || B <= 0 || A != 5)
+        !workspace || B <= 0 || A != 5 || n_valid <= 0 || n_valid > B)
         return TW_E_ARG;
     const int nblocks = (B + 255) / 256;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(ppo_loss_kernel<5>, dim3(nblocks), dim3(256), 0, st, probs, action, old_logp, adv, value,
-                       target_v, B, clip, ent_coef, grad_probs, grad_value, workspace);
-    hipLaunchKernelGGL(ppo_loss_finalize_kernel, dim3(1), dim3(64), 0, st, workspace, nblocks, B, losses);
+                       target_v, B, n_valid, clip, ent_coef, grad_probs, grad_value, workspace);
+    hipLaunchKernelGGL(ppo_loss_finalize_kernel, dim3(1), dim3(64), 0, st, workspace, nblocks, n_valid, losses);
     return check_launch();
 }
 

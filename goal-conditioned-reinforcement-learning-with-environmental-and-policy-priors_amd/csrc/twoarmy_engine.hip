@@ -71,9 +71,10 @@ constexpr int MATC_OFF = MAT_OFF + MAT_WORDS;    // 1448: byte image of the matr
 constexpr int MATC_BYTES = 304;                 // 289 + pad to 16
 constexpr int ENV_WORDS = MATC_OFF + MATC_BYTES / 4;   // 1524
 constexpr int STAGE_WORDS = 220;
-// record layout of the outputs (tw_alloc_outputs): one 2048-byte block per env-step, 292 floats of matrix then 880 bytes of image
-constexpr int REC_BYTES = 2048, REC_OBS_OFF = MAT_WORDS * 4;
-static_assert(REC_OBS_OFF + 880 == REC_BYTES, "matrix row + view-17 image row fill the record exactly");
+// record layout of the outputs (tw_alloc_outputs): one block per env-step = 292 floats of matrix, then the image row
+// (V*V*3 bytes rounded up to 16): 1168 + 880 = 2048 bytes for V = 17
+constexpr int REC_OBS_OFF = MAT_WORDS * 4;
+static_assert(REC_OBS_OFF + 880 == 2048, "matrix row + view-17 image row are exactly 2048 bytes");
 
 enum { R_STEP = 0, R_RISK = 1, R_HIT = 2, R_ROOM2 = 3, R_GOAL = 4 };
 
@@ -1709,8 +1710,9 @@ int launch_rollout(tw_engine *e, int T, const int32_t *actions, const uint32_t *
     if (obs_pitch > 0) p.obs_pitch = obs_pitch;
     if (mat_pitch > 0) p.mat_pitch = mat_pitch;
     if (p.obs_pitch < e->view * e->view * 3 || p.mat_pitch < NC) return TW_E_ARG;   // pitch: floats, or bytes with TW_F_MATRIX_CODE
-    p.record = !(flags & TW_F_MATRIX_CODE) && obs && matrix && p.obs_pitch == REC_BYTES && p.mat_pitch == REC_BYTES / 4 &&
-               obs == reinterpret_cast<uint8_t *>(matrix) + REC_OBS_OFF && ((uintptr_t)matrix & 127u) == 0;
+    p.record = !(flags & TW_F_MATRIX_CODE) && obs && matrix && p.obs_pitch == p.mat_pitch * 4 &&
+               obs == reinterpret_cast<uint8_t *>(matrix) + REC_OBS_OFF && ((uintptr_t)matrix & 15u) == 0 &&
+               p.obs_pitch >= REC_OBS_OFF + ((((e->view * e->view * 3) + 15) >> 4) << 4);
     const bool pipe = e->pipeline && T >= PIPE_MIN_T && (flags & TW_F_AUTORESET) && params_fast(e, p, true);
     if (!pipe) return launch_sequential(e, p, st);
     // pipelined launch: cur -> next, with the sequential kernel as a flag-gated fallback from the same input
@@ -2034,17 +2036,15 @@ int tw_alloc_outputs(tw_engine *e, int T, int flags, tw_outputs *out) {
     const size_t TN = (size_t)T * e->n_envs;
     const bool codes = (flags & TW_F_MATRIX_CODE) != 0;
     const int obs_row = ((e->view * e->view * 3 + 15) >> 4) << 4;
-    // float frames: ONE stream of 2048-byte records (matrix row | image row) -- two separate streams made the store
-    // bandwidth depend on where the driver happened to place them (0.178 ... 0.220 ms per launch);
-    // code frames (304-byte rows) keep two streams
-    const bool rec = !codes;
+    // ONE stream of records per env-step -- float frames: matrix row (1168 B) | image row, 2048 bytes for V = 17;
+    // code frames: image row | code row (304 B).  Two separate streams made the store bandwidth depend on where the
+    // driver happened to place them (0.178 ... 0.230 ms per launch).
     const size_t mat_row = codes ? (size_t)MATC_BYTES : (size_t)MAT_WORDS * 4;
+    const size_t rec_bytes = mat_row + (size_t)obs_row;
     const size_t A = (size_t)2 << 20;                 // every stream starts on a 2 MiB page
-    const size_t sz[6] = {rec ? TN * (size_t)REC_BYTES : TN * mat_row, rec ? 0 : TN * (size_t)obs_row, TN * 8, TN * 4, TN, TN};
+    const size_t sz[6] = {TN * rec_bytes, 0, TN * 8, TN * 4, TN, TN};
     size_t off[6], total = 0;
-    const char *gap_s = getenv("TW_SLAB_GAP_KB");          // diagnostic: extra gap between the matrix and the obs stream
-    const size_t gap = gap_s ? (size_t)atol(gap_s) << 10 : 0;
-    for (int i = 0; i < 6; ++i) { off[i] = total + (i >= 1 ? gap : 0); total = off[i] + round_up(sz[i], A); }
+    for (int i = 0; i < 6; ++i) { off[i] = total; total += round_up(sz[i], A); }
     // backing: mapped 2 MiB granules by default (TW_SLAB_BACKING=0..3 overrides); hipMalloc when the runtime refuses
     const char *bk = getenv("TW_SLAB_BACKING");
     int backing = bk ? atoi(bk) : e->slab_backing;
@@ -2053,9 +2053,11 @@ int tw_alloc_outputs(tw_engine *e, int T, int flags, tw_outputs *out) {
     if (rc != TW_OK && backing != 0) { backing = 0; rc = slab_alloc(e->device, total, 0, s); }
     if (rc != TW_OK) return rc;
     char *b = (char *)s.base;
-    out->matrix = b + off[0]; out->obs = (uint8_t *)(rec ? b + off[0] + REC_OBS_OFF : b + off[1]); out->pos = (float *)(b + off[2]);
+    out->matrix = codes ? b + off[0] + obs_row : b + off[0];
+    out->obs = (uint8_t *)(codes ? b + off[0] : b + off[0] + REC_OBS_OFF);
+    out->pos = (float *)(b + off[2]);
     out->reward = (float *)(b + off[3]); out->terminated = (uint8_t *)(b + off[4]); out->truncated = (uint8_t *)(b + off[5]);
-    out->obs_pitch = rec ? REC_BYTES : obs_row; out->mat_pitch = codes ? MATC_BYTES : (rec ? REC_BYTES / 4 : MAT_WORDS);
+    out->obs_pitch = (int)rec_bytes; out->mat_pitch = codes ? (int)rec_bytes : (int)(rec_bytes / 4);
     out->T = T; out->n_envs = e->n_envs; out->flags = flags & TW_F_MATRIX_CODE; out->device = e->device;
     out->backing = s.backing; out->slab_bytes = s.bytes; out->slab = s.base;
     std::lock_guard<std::mutex> lk(g_slab_mu);

@@ -12,7 +12,6 @@ from ._lib import FIELDS, TW_CELLS, TW_DRAW_WORDS, TW_F_AUTORESET, TW_F_MATRIX_C
 
 REWARD_VALUES = (-0.01, -0.1, -0.9, 0.2, 0.9)
 MAT_PITCH = 292                       # floats per env matrix in the native layout (289 + 3 zero pad)
-REC_BYTES = 2048                      # record layout of tw_alloc_outputs: 292 floats of matrix | 880 bytes of image per env-step
 MATC_PITCH = 304                      # bytes per env matrix in the code layout (TW_F_MATRIX_CODE; 289 + 15 pad)
 MATRIX_CODE_VALUES = (0.9, -0.9, -0.5, 0.3)     # code -> Env_transact.matrix_env value (free/goal, wall, ball, agent)
 
@@ -209,16 +208,19 @@ class TwoarmyEngine:
         o = owner.out
         TN = (1 if T is None else T) * N
         nb = V * V * 3
+        # one stream of records (include/twoarmy.h): float frames = matrix row | image row, code frames = image row | code row
+        rb = int(o.obs_pitch)
+        rec = owner.tensor(min(o.obs, o.matrix), TN * rb, torch.uint8).view(lead + (rb,))
+        orow = obs_pitch_for(V)
         if matrix_codes:
-            obs = owner.tensor(o.obs, TN * o.obs_pitch, torch.uint8).view(lead + (o.obs_pitch,))[..., :nb].view(lead + (V, V, 3))
-            m = owner.tensor(o.matrix, TN * o.mat_pitch, torch.uint8).view(lead + (o.mat_pitch,))[..., :TW_CELLS]
+            assert o.matrix == o.obs + orow and o.mat_pitch == rb == orow + MATC_PITCH
+            obs = rec[..., :nb].view(lead + (V, V, 3))
+            m = rec[..., orow:orow + TW_CELLS]
         else:
-            # record layout: [*lead] blocks of REC_BYTES = 292 floats of matrix | 880 bytes of image (include/twoarmy.h)
-            assert o.obs_pitch == REC_BYTES and o.mat_pitch * 4 == REC_BYTES and o.obs == o.matrix + MAT_PITCH * 4
-            rec = owner.tensor(o.matrix, TN * REC_BYTES, torch.uint8).view(lead + (REC_BYTES,))
+            assert o.obs == o.matrix + MAT_PITCH * 4 and o.mat_pitch * 4 == rb == MAT_PITCH * 4 + orow
             m = rec[..., :MAT_PITCH * 4].view(torch.float32)[..., :TW_CELLS]
             obs = rec[..., MAT_PITCH * 4:MAT_PITCH * 4 + nb].view(lead + (V, V, 3))
-        m._tw_layout = ("code frames, two streams" if matrix_codes else "2048-byte records (matrix | image)") + \
+        m._tw_layout = ("%d-byte records (image | codes)" % rb if matrix_codes else "%d-byte records (matrix | image)" % rb) + \
             (", hipMalloc" if o.backing == 0 else ", 2 MiB mapped chunks")
         return dict(obs=obs, matrix=m,
                     pos=owner.tensor(o.pos, TN * 8, torch.float32).view(lead + (2,)),

@@ -63,11 +63,12 @@ class _AttachGrad(torch.autograd.Function):
         return (grad * g).view(ctx.xshape), None, None
 
 
-def ppo_losses(probs, value, action, old_logp, adv, target_v, clip=0.1, ent_coef=0.01):
+def ppo_losses(probs, value, action, old_logp, adv, target_v, clip=0.1, ent_coef=0.01, n_valid=None):
     """(action_loss, value_loss) of the reference (PPO.py:124-133).  One fused forward+backward launch;
     the two losses are separate autograd nodes so `action_loss.backward(); value_loss.backward()` works
-    exactly like in the reference."""
+    exactly like in the reference.  n_valid < B: rows n_valid.. are padding of a fixed-shape minibatch."""
     B, A = probs.shape
+    n_valid = B if n_valid is None else int(n_valid)
     with torch.no_grad():
         probs_c = probs.detach().contiguous()
         value_c = value.detach().contiguous().view(-1)
@@ -75,10 +76,10 @@ def ppo_losses(probs, value, action, old_logp, adv, target_v, clip=0.1, ent_coef
         gp = torch.empty_like(probs_c)
         gv = torch.empty_like(value_c)
         ws = torch.empty(2 * ((B + 255) // 256), dtype=torch.float32, device=probs.device)
-        _lib.check(_lib.lib().ppo_loss_fwd_bwd(
+        _lib.check(_lib.lib().ppo_loss_fwd_bwd_masked(
             _p(probs_c, torch.float32), _p(action.contiguous(), torch.int32), _p(old_logp.contiguous().view(-1)),
-            _p(adv.contiguous().view(-1)), _p(value_c), _p(target_v.contiguous().view(-1)), B, A, float(clip),
-            float(ent_coef), _p(losses), _p(gp), _p(gv), _p(ws), _stream(probs)), "ppo_loss_fwd_bwd")
+            _p(adv.contiguous().view(-1)), _p(value_c), _p(target_v.contiguous().view(-1)), B, n_valid, A, float(clip),
+            float(ent_coef), _p(losses), _p(gp), _p(gv), _p(ws), _stream(probs)), "ppo_loss_fwd_bwd_masked")
     return _AttachGrad.apply(probs, losses[0], gp), _AttachGrad.apply(value, losses[1], gv)
 
 

@@ -156,16 +156,17 @@ class PPO:
                                      gamma=self.gamma, lam=0.0, use_done_mask=False, want_ret=False)
         return adv.view(n, 1), target.view(n, 1)
 
-    def minibatch_step(self, s0, p0, g, a, old_logp, adv, target_v):
-        """One optimiser step on one minibatch (PPO.py:122-147); returns (action_loss, value_loss) tensors."""
-        return self.minibatch_step_x(self.policy_input(s0), p0, g, a, old_logp, adv, target_v)
+    def minibatch_step(self, s0, p0, g, a, old_logp, adv, target_v, n_valid=None):
+        """One optimiser step on one minibatch (PPO.py:122-147); returns (action_loss, value_loss) tensors.
+        n_valid: the first n_valid rows are real samples, the rest pads the minibatch to a fixed shape."""
+        return self.minibatch_step_x(self.policy_input(s0), p0, g, a, old_logp, adv, target_v, n_valid)
 
-    def minibatch_step_x(self, x0, p0, g, a, old_logp, adv, target_v):
+    def minibatch_step_x(self, x0, p0, g, a, old_logp, adv, target_v, n_valid=None):
         """minibatch_step on already assembled network inputs (frames incl. any predicted ones)."""
         probs = self.actor_probs(x0, p0, g)
         value = self.critic_value(x0, p0, g)
         action_loss, value_loss = ppo_ops.ppo_losses(probs, value, a, old_logp, adv, target_v,
-                                                     clip=self.clip_param, ent_coef=self.entropy_coef)
+                                                     clip=self.clip_param, ent_coef=self.entropy_coef, n_valid=n_valid)
         self.optimizer_actor.zero_grad()
         self.optimizer_critic.zero_grad()
         action_loss.backward()

@@ -31,6 +31,7 @@ class VecPPOTrainer:
         T, N = self.T, self.N
         self.frame_codes = bool(frame_codes)
         self.reuse_next_values = True             # V(s'_t) = V(s_{t+1}) inside an episode (_values_rollout)
+        self.fixed_shapes = True                  # pad partial minibatches / value chunks to the full size (masked rows)
         self.time_phases = False                  # update(): wall time of target computation vs epochs (one extra sync)
         self.last_update_timing = None
         if self.frame_codes:
@@ -164,10 +165,15 @@ class VecPPOTrainer:
         total = t_idx.numel()
         v = torch.empty(total, device=self.device)
         self.agent.critic.eval()
-        for i in range(0, total, self.value_chunk):
-            sl = slice(i, min(total, i + self.value_chunk))
+        C = self.value_chunk
+        for i in range(0, total, C):
+            sl = torch.arange(i, min(total, i + C), device=self.device)
+            n_real = sl.numel()
+            if self.fixed_shapes and n_real < C and total >= C:
+                sl = torch.cat([sl, sl[torch.arange(C - n_real, device=self.device) % n_real]])   # pad: one conv batch size
             s, p = self._stacks(t_idx[sl], n_idx[sl], after=after)
-            v[sl] = self.agent.critic_value(self.agent.policy_input(s), p, self.goal_input(goal[sl], after)).view(-1)
+            out = self.agent.critic_value(self.agent.policy_input(s), p, self.goal_input(goal[sl], after)).view(-1)
+            v[i:i + n_real] = out[:n_real]
         return v
 
     def _values(self, t_idx, n_idx, goal):
@@ -252,9 +258,15 @@ class VecPPOTrainer:
             done_steps = 0
             for i in range(0, perm.numel(), self.minibatch):
                 idx = perm[i:i + self.minibatch]
+                n_valid = None
+                if self.fixed_shapes and idx.numel() < self.minibatch <= perm.numel():
+                    # the epoch's last, partial minibatch: padded to the full shape with masked rows (same loss and
+                    # gradients; a new batch size would cost a MIOpen kernel search -- seconds -- every update)
+                    n_valid = idx.numel()
+                    idx = torch.cat([idx, idx[torch.arange(self.minibatch - n_valid, device=self.device) % n_valid]])
                 s0, p0 = self._stacks(smp_t[idx], smp_n[idx], after=False)
                 la, lv = ag.minibatch_step(s0, p0, self.goal_input(smp_goal[idx], False), act[idx],
-                                           logp[idx].view(-1, 1), adv[idx].view(-1, 1), target[idx].view(-1, 1))
+                                           logp[idx].view(-1, 1), adv[idx].view(-1, 1), target[idx].view(-1, 1), n_valid)
                 done_steps += 1
             assert done_steps == n_steps or not synced, (done_steps, n_steps)
         if ag.use_lr_decay:

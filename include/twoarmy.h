@@ -151,13 +151,15 @@ const char *tw_version(void);
  * all carved out of ONE device slab.  This is the counterpart of the arrays the reference's rollout loop appends to
  * (soa/train_ppo.py:116-123 stack pushes, Buffer_gridworld.store env_buffer.py:68-77): every user of the library --
  * the Python trainer, the vector env, a C caller -- gets the same placement without probing candidates.
- * Float frames use the RECORD layout: one stream of 2048-byte blocks, one per env-step,
- *   [T][N] x { float matrix[292] (289 + 3 zero pad) | uint8 image[880] (V*V*3 + zero pad) }
- * i.e. matrix = slab, mat_pitch = 512 floats; obs = slab + 1168, obs_pitch = 2048 bytes.  tw_rollout recognises these
- * pointers / pitches and writes every block with two full-wave stores of eight whole 128-byte lines each.  (Two
- * separate streams, which the API still accepts, make the store bandwidth depend on where the driver happens to place
- * them: 0.178 ... 0.220 ms per 4096 x 128 launch; the record stream is 0.19 ms on every allocation.)
- * With TW_F_MATRIX_CODE: obs uint8 [T][N][880] and matrix uint8 [T][N][304] as two streams, mat_pitch in bytes.
+ * Frames and images use the RECORD layout: ONE stream of blocks, one per env-step,
+ *   float frames   [T][N] x { float matrix[292] (289 + 3 zero pad) | uint8 image[R] }      R = roundup(V*V*3, 16)
+ *                  matrix = slab, obs = slab + 1168, obs_pitch = 1168 + R bytes, mat_pitch = obs_pitch / 4 floats
+ *                  (V = 17: R = 880, 2048-byte blocks, each written by two full-wave stores of eight whole 128-byte lines)
+ *   code frames    [T][N] x { uint8 image[R] | uint8 codes[304] }  (TW_F_MATRIX_CODE)
+ *                  obs = slab, matrix = slab + R, obs_pitch = mat_pitch = R + 304 bytes
+ * tw_rollout recognises these pointers / pitches.  (Two separate streams, which the API still accepts, make the store
+ * bandwidth depend on where the driver happens to place them: 0.178 ... 0.230 ms per 4096 x 128 launch; the record
+ * stream is 0.19-0.20 ms on every allocation.)
  *   pos float[T][N][2], reward float[T][N], terminated / truncated uint8[T][N]   (dense)
  * `backing`: how the slab is backed -- 1 (default) = 2 MiB physical chunks (hipMemCreate) mapped into one virtual range,
  * 0 = hipMalloc (also the fallback when the runtime refuses the mapping calls).  Pass the struct's members to tw_step / tw_rollout.  tw_free_outputs releases the slab

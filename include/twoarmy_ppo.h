@@ -54,6 +54,13 @@ int ppo_adv_norm(float *adv, int64_t n, float eps, double *workspace, void *stre
 int ppo_loss_fwd_bwd(const float *probs, const int32_t *action, const float *old_logp, const float *adv,
                      const float *value, const float *target_v, int B, int A, float clip, float ent_coef,
                      float *losses, float *grad_probs, float *grad_value, float *workspace, void *stream);
+/* The same for a minibatch padded to a fixed shape: rows n_valid .. B-1 are padding (they carry no loss and get zero
+ * gradients; the means run over the n_valid real rows).  Keeps every conv launch of an update at ONE batch size:
+ * MIOpen searches kernels per shape, and an odd last minibatch costs a new multi-second search. */
+int ppo_loss_fwd_bwd_masked(const float *probs, const int32_t *action, const float *old_logp, const float *adv,
+                            const float *value, const float *target_v, int B, int n_valid, int A, float clip,
+                            float ent_coef, float *losses, float *grad_probs, float *grad_value, float *workspace,
+                            void *stream);
 
 /* Policy-input assembly from time-major frames (replaces the 5-deep np.delete/np.append stacks of
  * train_ppo.py:116-121 and the [0:4] / [1:5] slices of PPO.py:113-114,124).  For sample b with newest

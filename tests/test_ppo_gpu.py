@@ -255,3 +255,24 @@ def test_fused_upsample_conv1_vs_torch(F):
     gw, gb = torch.autograd.grad(y, (w, b), gy)
     # the ReLU mask may differ where |pre-activation| < 1e-5 (summation order); none of these random cases is that close
     assert torch.allclose(gw, gw_ref, atol=2e-3, rtol=1e-4) and torch.allclose(gb, gb_ref, atol=1e-3, rtol=1e-5)
+
+
+def test_masked_fixed_shape_loss_equals_unpadded():
+    """ppo_loss_fwd_bwd_masked: a minibatch padded to a fixed shape (rows n_valid.. are padding) has exactly the losses
+    and gradients of the unpadded minibatch; padding rows get zero gradients."""
+    from twoarmy_amd import ppo_ops
+    torch.manual_seed(5)
+    B, P = 300, 212
+    probs = torch.softmax(torch.randn(B + P, 5, device=DEV), 1).requires_grad_(True)
+    value = torch.randn(B + P, 1, device=DEV, requires_grad=True)
+    a = torch.randint(0, 5, (B + P,), device=DEV, dtype=torch.int32)
+    old = torch.randn(B + P, 1, device=DEV) * 0.1 - 1.6
+    adv, tgt = torch.randn(B + P, 1, device=DEV), torch.randn(B + P, 1, device=DEV)
+    la, lv = ppo_ops.ppo_losses(probs, value, a, old, adv, tgt, n_valid=B)
+    gp, gv = torch.autograd.grad(la + lv, (probs, value))
+    p2, v2 = probs.detach()[:B].clone().requires_grad_(True), value.detach()[:B].clone().requires_grad_(True)
+    la2, lv2 = ppo_ops.ppo_losses(p2, v2, a[:B], old[:B], adv[:B], tgt[:B])
+    gp2, gv2 = torch.autograd.grad(la2 + lv2, (p2, v2))
+    assert float(la) == float(la2) and float(lv) == float(lv2)
+    assert torch.equal(gp[:B], gp2) and torch.equal(gv[:B], gv2)
+    assert float(gp[B:].abs().max()) == 0.0 and float(gv[B:].abs().max()) == 0.0

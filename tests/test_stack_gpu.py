@@ -312,3 +312,31 @@ def test_full_size_config2_collect_replay_and_minibatch():
     want_lv = float(np.mean(np.where(np.abs(dv) < 1, 0.5 * dv * dv, np.abs(dv) - 0.5), dtype=np.float64))
     assert abs(float(la) - want_la) < 1e-5 and abs(float(lv) - want_lv) < 1e-5
     eng.close(); eng2.close()
+
+
+def test_fixed_shape_padding_changes_nothing():
+    """VecPPOTrainer pads the epoch's last minibatch and the last value chunk to the full shape (masked rows) so that
+    every conv launch of an update has one batch size: targets and losses agree within 1e-5 (a different batch size
+    makes MIOpen pick a different kernel, i.e. a different fp32 summation order; the masked loss kernel itself is exact,
+    tests/test_ppo_gpu.py::test_masked_fixed_shape_loss_equals_unpadded)."""
+    from twoarmy_amd.engine import TwoarmyEngine
+    from twoarmy_amd.soa.agent.PPO import PPO
+    from twoarmy_amd.soa.ppo_vec import VecPPOTrainer
+    N, T = 48, 50
+    out = []
+    for fixed in (False, True):
+        torch.manual_seed(11)
+        eng = TwoarmyEngine(4, N, 17, seed=SEED)
+        agent = PPO()
+        agent.K_epochs = 1
+        tr = VecPPOTrainer(agent, eng, rollout_steps=T, minibatch=1024, value_chunk=1024)
+        tr.fixed_shapes = fixed
+        g = torch.Generator(device="cpu").manual_seed(3)
+        tr.collect(uniforms=torch.rand(T, N, generator=g).to(tr.device))
+        adv, target = tr.compute_targets()
+        la, lv = tr.update(permutations=[torch.randperm(T * N, generator=g)])
+        out.append((adv.clone(), target.clone(), float(la), float(lv)))
+        eng.close()
+    (a0, t0, la0, lv0), (a1, t1, la1, lv1) = out
+    assert torch.allclose(a0, a1, atol=2e-5) and torch.allclose(t0, t1, atol=2e-5)
+    assert abs(la0 - la1) < 1e-5 and abs(lv0 - lv1) < 1e-5
