@@ -164,6 +164,74 @@ __global__ __launch_bounds__(256) void ppo_conv1_up4_kernel(const float *__restr
     }
 }
 
+// Backward of the fused first layer: gw_folded[py][px][ty][tx][c][64] = sum over samples and over the output pixels of
+// parity (py, px) of x[c][m+ty][n+tx] * g[pixel][64], g = gy where the layer's output y is positive (ReLU), and the bias
+// gradient sum of g -- gy and y are read exactly once, nothing else of the 33x33x64 size is touched (the separate
+// ReLU-backward pass + MIOpen weight-gradient conv on re-upsampled frames read and wrote it four times).
+// Grid = (groups, 4 parities); a block walks samples blockIdx.x, +groups, ...; block = 16 channel quads x 16 pixel slots,
+// 4 taps x F float4 accumulators per thread, combined over the 16 slots through LDS in a fixed order; per-block partial
+// sums (deterministic), the caller adds the groups.
+template <int F>
+__global__ __launch_bounds__(256) void ppo_conv1_up4_bwd_kernel(const float *__restrict__ frames, const float4 *__restrict__ gy,
+                                                                const float4 *__restrict__ y, float4 *__restrict__ gw_part,
+                                                                float4 *__restrict__ gb_part, int B) {
+    __shared__ float xs[F * 18 * 18];
+    __shared__ float4 red[256];
+    const int tid = threadIdx.x, cq = tid & 15, slot = tid >> 4;
+    const int ph = blockIdx.y, py = ph >> 1, px = ph & 1;
+    const int ny = 17 - py, nx = 17 - px;
+    float4 acc[4 * F];
+#pragma unroll
+    for (int k = 0; k < 4 * F; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 accb = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();                                    // the previous sample's xs is no longer read
+        const float *src = frames + (size_t)b * F * 289;
+        for (int i = tid; i < F * 324; i += 256) {
+            const int c = i / 324, r = i - c * 324, yy = r / 18, xx = r - yy * 18;
+            xs[i] = (yy < 17 && xx < 17) ? src[c * 289 + yy * 17 + xx] : 0.f;
+        }
+        __syncthreads();
+        const size_t base = (size_t)b * 1089 * 16;
+        for (int q = slot; q < ny * nx; q += 16) {
+            const int m = q / nx, n = q - m * nx;
+            const size_t o = base + (size_t)((2 * m + py) * 33 + 2 * n + px) * 16 + cq;
+            const float4 gv = gy[o], yv = y[o];
+            float4 g;
+            g.x = yv.x > 0.f ? gv.x : 0.f; g.y = yv.y > 0.f ? gv.y : 0.f;
+            g.z = yv.z > 0.f ? gv.z : 0.f; g.w = yv.w > 0.f ? gv.w : 0.f;
+            accb.x += g.x; accb.y += g.y; accb.z += g.z; accb.w += g.w;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int ty = t >> 1, tx = t & 1;
+#pragma unroll
+                for (int c = 0; c < F; ++c) {
+                    const float xv = xs[c * 324 + (m + ty) * 18 + n + tx];
+                    float4 &a = acc[t * F + c];
+                    a.x = fmaf(xv, g.x, a.x); a.y = fmaf(xv, g.y, a.y); a.z = fmaf(xv, g.z, a.z); a.w = fmaf(xv, g.w, a.w);
+                }
+            }
+        }
+    }
+    // combine the 16 pixel slots (fixed order), one accumulator at a time
+    const size_t wbase = ((size_t)blockIdx.x * 4 + ph) * (4 * F) * 16;
+#pragma unroll
+    for (int k = 0; k <= 4 * F; ++k) {
+        __syncthreads();
+        red[tid] = k < 4 * F ? acc[k < 4 * F ? k : 0] : accb;
+        __syncthreads();
+        if (slot == 0) {
+            float4 sum = red[cq];
+            for (int r = 1; r < 16; ++r) {
+                const float4 o = red[r * 16 + cq];
+                sum.x += o.x; sum.y += o.y; sum.z += o.z; sum.w += o.w;
+            }
+            if (k < 4 * F) gw_part[wbase + (size_t)k * 16 + cq] = sum;
+            else gb_part[((size_t)blockIdx.x * 4 + ph) * 16 + cq] = sum;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ GAE: segmented reverse scan
 // Block = 256 threads = 4 waves, GN envs (columns) x chunks of 64 time steps walked from T backwards (GN = 16 for
 // N < 16384 so that a 4096-env rollout still fills 256 workgroups; 64 otherwise).
@@ -644,6 +712,29 @@ int ppo_conv1_up4_bias_relu(const float *frames, int B, int F, const float *fold
     else if (F == 8)
         hipLaunchKernelGGL(ppo_conv1_up4_kernel<8>, dim3(B), dim3(256), 0, st, frames, reinterpret_cast<const float4 *>(folded_w),
                            reinterpret_cast<const float4 *>(bias), reinterpret_cast<float4 *>(out), B);
+    else
+        return TW_E_ARG;
+    return check_launch();
+}
+
+int ppo_conv1_up4_bwd_groups(int B) { return B <= 0 ? TW_E_ARG : (B < 256 ? B : 256); }
+
+int ppo_conv1_up4_bwd(const float *frames, int B, int F, const float *gy, const float *y, float *gw_partial,
+                      float *gb_partial, void *stream) {
+    const int groups = ppo_conv1_up4_bwd_groups(B);
+    if (groups <= 0 || !frames || !gy || !y || !gw_partial || !gb_partial ||
+        (((uintptr_t)gy | (uintptr_t)y | (uintptr_t)gw_partial | (uintptr_t)gb_partial) & 15u))
+        return TW_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(groups, 4), block(256);
+    if (F == 4)
+        hipLaunchKernelGGL(ppo_conv1_up4_bwd_kernel<4>, grid, block, 0, st, frames, reinterpret_cast<const float4 *>(gy),
+                           reinterpret_cast<const float4 *>(y), reinterpret_cast<float4 *>(gw_partial),
+                           reinterpret_cast<float4 *>(gb_partial), B);
+    else if (F == 8)
+        hipLaunchKernelGGL(ppo_conv1_up4_bwd_kernel<8>, grid, block, 0, st, frames, reinterpret_cast<const float4 *>(gy),
+                           reinterpret_cast<const float4 *>(y), reinterpret_cast<float4 *>(gw_partial),
+                           reinterpret_cast<float4 *>(gb_partial), B);
     else
         return TW_E_ARG;
     return check_launch();

@@ -192,9 +192,9 @@ def fold_conv1_weights(w):
 
 
 class _Conv1Up4(torch.autograd.Function):
-    """relu(conv1(upsample_x4(frames)) + b) in one kernel (ppo_conv1_up4_bias_relu); backward = ReLU mask + bias
-    gradient (ppo_relu_bwd_bias_grad_nhwc) and MIOpen's weight-gradient conv on the upsampled frames, which are only
-    materialised there (the frames themselves need no gradient)."""
+    """relu(conv1(upsample_x4(frames)) + b) in one kernel (ppo_conv1_up4_bias_relu); backward in one kernel too
+    (ppo_conv1_up4_bwd: ReLU mask, folded weight gradient and bias gradient from one read of gy and y; the frames
+    themselves need no gradient)."""
 
     @staticmethod
     def forward(ctx, frames, w, b):
@@ -212,19 +212,25 @@ class _Conv1Up4(torch.autograd.Function):
     def backward(ctx, gy):
         fr, w, y = ctx.saved_tensors
         gy = gy.contiguous(memory_format=torch.channels_last)
-        B, Cc, H, W = y.shape
-        npix = B * H * W
-        blocks = _lib.lib().ppo_relu_bwd_bias_grad_nhwc_blocks(npix, Cc)
-        g = torch.empty_like(y)
-        partial = torch.empty((blocks, Cc), dtype=torch.float32, device=y.device)
-        _lib.check(_lib.lib().ppo_relu_bwd_bias_grad_nhwc(C.c_void_p(gy.data_ptr()), C.c_void_p(y.data_ptr()),
-                                                          C.c_void_p(g.data_ptr()), _p(partial), npix, Cc, _stream(y)),
-                   "ppo_relu_bwd_bias_grad_nhwc")
-        x_up = torch.nn.functional.interpolate(fr.view(B, -1, 17, 17).contiguous(memory_format=torch.channels_last),
-                                               scale_factor=4, mode="nearest")
-        _, gw, _ = torch.ops.aten.convolution_backward(g, x_up, w, None, [2, 2], [0, 0], [1, 1], False, [0, 0], 1,
-                                                       [False, True, False])
-        return None, gw, partial.sum(0)
+        B, F = fr.shape[0], fr.shape[1]
+        groups = _lib.lib().ppo_conv1_up4_bwd_groups(B)
+        gw_part = torch.empty((groups, 2, 2, 2, 2, F, 64), dtype=torch.float32, device=y.device)
+        gb_part = torch.empty((groups, 4, 64), dtype=torch.float32, device=y.device)
+        _lib.check(_lib.lib().ppo_conv1_up4_bwd(_p(fr, torch.float32), B, F, C.c_void_p(gy.data_ptr()), C.c_void_p(y.data_ptr()),
+                                                _p(gw_part), _p(gb_part), _stream(y)), "ppo_conv1_up4_bwd")
+        return None, unfold_conv1_grad(gw_part.sum(0)).to(w.dtype), gb_part.sum((0, 1))
+
+
+def unfold_conv1_grad(gwf):
+    """Gradient w.r.t. the folded weights [py][px][ty][tx][F][O] -> gradient w.r.t. W[O][F][4][4] (transpose of
+    fold_conv1_weights: row r of W feeds tap 0 of parity 0 and tap r // 2 of parity 1; columns alike)."""
+    ty = torch.tensor([[0, 0, 0, 0], [0, 0, 1, 1]], device=gwf.device)              # [py][r]
+    out = None
+    for py in (0, 1):
+        for px in (0, 1):
+            g = gwf[py, px][ty[py]][:, ty[px]]                                        # [r][k][F][O]
+            out = g if out is None else out + g
+    return out.permute(3, 2, 0, 1).contiguous()
 
 
 def conv1_up4_bias_relu(frames, weight, bias):

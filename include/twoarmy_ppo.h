@@ -132,6 +132,15 @@ int ppo_relu_bwd_bias_grad_nhwc(const float *gy, const float *y, float *gx, floa
 int ppo_conv1_up4_bias_relu(const float *frames, int B, int F, const float *folded_w, const float *bias, float *out,
                             void *stream);
 
+/* Backward of ppo_conv1_up4_bias_relu w.r.t. the folded weights and the bias (the frames carry no gradient):
+ *   g = gy * (y > 0);  gw_partial[group][2][2][2][2][F][64] / gb_partial[group][4][64] = per-block partial sums over the
+ *   samples a group walks (groups = ppo_conv1_up4_bwd_groups(B); the caller adds groups -- and, for the bias, the four
+ *   parities --, then maps the folded gradient back onto W[64][F][4][4]: dW[o][c][r][k] = sum over parities of
+ *   gw[py][px][py ? r/2 : 0][px ? k/2 : 0][c][o]).  gy, y: float[B][33][33][64] channels-last, y = the layer's output. */
+int ppo_conv1_up4_bwd_groups(int B);
+int ppo_conv1_up4_bwd(const float *frames, int B, int F, const float *gy, const float *y, float *gw_partial,
+                      float *gb_partial, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
