@@ -74,3 +74,19 @@ def broadcast_parameters(modules, src=0):
     for m in modules:
         for t in list(m.parameters()) + list(m.buffers()):
             dist.broadcast(t.data, src)
+
+
+def global_adv_norm_(adv, eps=1e-8):
+    """adv <- (adv - mean) / (std + eps) with mean / unbiased std over the samples of ALL ranks (the reference's
+    commented normalisation, PPO.py:115, applied to the whole sharded batch): one all-reduce of (count, sum, sum of
+    squares) in float64 -- SURVEY.md section 8e's optional second collective.  Works on any device / backend."""
+    a = adv.double()
+    st = torch.stack([torch.tensor(float(a.numel()), dtype=torch.float64, device=adv.device), a.sum(), (a * a).sum()])
+    on_cpu = dist.get_backend() != "nccl"
+    red = st.cpu() if on_cpu else st
+    dist.all_reduce(red, op=dist.ReduceOp.SUM)
+    n, s1, s2 = (float(x) for x in red)
+    mean = s1 / n
+    var = max(0.0, (s2 - n * mean * mean) / max(1.0, n - 1.0))
+    adv.sub_(mean).div_(var ** 0.5 + eps)
+    return adv

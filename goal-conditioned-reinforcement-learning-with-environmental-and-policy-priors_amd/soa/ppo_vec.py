@@ -218,7 +218,12 @@ class VecPPOTrainer:
             adv = torch.cat([adv, hadv.view(-1)])
             critic_target = torch.cat([critic_target, htarget.view(-1)])
         if self.agent.normalize_adv:
-            ppo_ops.adv_norm_(adv)
+            if self.agent.grad_sync is not None and torch.distributed.is_initialized() and \
+                    torch.distributed.get_world_size() > 1:
+                from .. import dist as twdist
+                twdist.global_adv_norm_(adv)                      # statistics over every rank's samples
+            else:
+                ppo_ops.adv_norm_(adv)
         return adv, critic_target
 
     def update(self, permutations=None):

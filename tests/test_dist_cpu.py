@@ -62,3 +62,36 @@ def test_shard_range_partitions_exactly():
             spans = [shard_range(total, r, world) for r in range(world)]
             assert spans[0][0] == 0 and spans[-1][1] == total
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+
+
+def _norm_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from twoarmy_amd import dist as twdist
+    twdist.init_from_env(backend="gloo")
+    g = torch.Generator().manual_seed(7)
+    full = torch.randn(1000, generator=g) * 3 + 1
+    mine = full[:300].clone() if rank == 0 else full[300:].clone()      # unequal shards
+    twdist.global_adv_norm_(mine)
+    q.put((rank, mine.tolist()))
+    dist.destroy_process_group()
+
+
+def test_global_advantage_normalisation_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_norm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(7)
+    full = torch.randn(1000, generator=g) * 3 + 1
+    want = (full - full.mean()) / (full.std() + 1e-8)                   # torch unbiased std, like PPO.py:115
+    got = torch.tensor(res[0] + res[1])
+    assert torch.allclose(got, want, atol=1e-5)
