@@ -17,6 +17,7 @@ TW_DRAW_WORDS = 8
 TW_F_AUTORESET = 1
 TW_F_POLICY_IDX = 2
 TW_F_MATRIX_CODE = 4
+TW_F_SLAB_HIPMALLOC = 8
 
 # enum tw_field (include/twoarmy.h)
 FIELDS = dict(AX=0, AY=1, DIR=2, STEP_COUNT=3, STEP_MOVE=4, PONE=5, PATROL=6, UP1=7, RIGHT2=8, UPD_LONG=9,

@@ -2048,6 +2048,7 @@ int tw_alloc_outputs(tw_engine *e, int T, int flags, tw_outputs *out) {
     // backing: mapped 2 MiB granules by default (TW_SLAB_BACKING=0..3 overrides); hipMalloc when the runtime refuses
     const char *bk = getenv("TW_SLAB_BACKING");
     int backing = bk ? atoi(bk) : e->slab_backing;
+    if (flags & TW_F_SLAB_HIPMALLOC) backing = 0;
     Slab s;
     int rc = slab_alloc(e->device, total, backing, s);
     if (rc != TW_OK && backing != 0) { backing = 0; rc = slab_alloc(e->device, total, 0, s); }

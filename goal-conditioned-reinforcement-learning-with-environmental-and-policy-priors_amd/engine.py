@@ -8,7 +8,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import FIELDS, TW_CELLS, TW_DRAW_WORDS, TW_F_AUTORESET, TW_F_MATRIX_CODE, TW_F_POLICY_IDX, TW_REC_WORDS
+from ._lib import (FIELDS, TW_CELLS, TW_DRAW_WORDS, TW_F_AUTORESET, TW_F_MATRIX_CODE, TW_F_POLICY_IDX, TW_F_SLAB_HIPMALLOC,
+                   TW_REC_WORDS)
 
 REWARD_VALUES = (-0.01, -0.1, -0.9, 0.2, 0.9)
 MAT_PITCH = 292                       # floats per env matrix in the native layout (289 + 3 zero pad)
@@ -93,6 +94,9 @@ class _OutputSlab:
 
     def tensor(self, ptr, nbytes, dtype):
         t = torch.as_tensor(_DevSpan(self, ptr, nbytes), device=self.device)
+        if t.data_ptr() != int(ptr) or t.device != self.device:
+            raise _lib.TwoarmyLibraryError("torch did not alias the engine slab (got %s at %#x for %#x on %s)"
+                                           % (t.device, t.data_ptr(), int(ptr), self.device))
         return t.view(dtype)
 
     def __del__(self):
@@ -204,7 +208,14 @@ class TwoarmyEngine:
 
     def _slab_outputs(self, T, lead, matrix_codes):
         N, V = self.num_envs, self.view_size
-        owner = _OutputSlab(self, 1 if T is None else T, TW_F_MATRIX_CODE if matrix_codes else 0)
+        flags = TW_F_MATRIX_CODE if matrix_codes else 0
+        owner = _OutputSlab(self, 1 if T is None else T, flags)
+        try:
+            owner.tensor(min(owner.out.obs, owner.out.matrix), 16, torch.uint8)
+        except _lib.TwoarmyLibraryError:
+            # a mapped slab torch cannot wrap in place (seen nowhere so far; multi-GPU ranks are the untested case):
+            # the same layout from plain hipMalloc memory, whose pointer attributes torch certainly understands
+            owner = _OutputSlab(self, 1 if T is None else T, flags | TW_F_SLAB_HIPMALLOC)
         o = owner.out
         TN = (1 if T is None else T) * N
         nb = V * V * 3

@@ -44,6 +44,8 @@ extern "C" {
                                  3 agent (0.3) -- instead of float[289]; exact (the matrix is a 4-entry LUT) and 4x smaller.
                                  ppo_gather_stack_u8 expands it back to fp32 policy inputs. */
 
+#define TW_F_SLAB_HIPMALLOC 8 /* tw_alloc_outputs only: back the slab with plain hipMalloc instead of mapped 2 MiB chunks */
+
 /* per-env scalar record, int32 words (AoS: one 192-byte record per env) */
 enum tw_field {
     TW_AX = 0, TW_AY, TW_DIR,                 /* agent_pos, agent_dir (minigrid.py:927-928) */

@@ -340,3 +340,32 @@ def test_fixed_shape_padding_changes_nothing():
     (a0, t0, la0, lv0), (a1, t1, la1, lv1) = out
     assert torch.allclose(a0, a1, atol=2e-5) and torch.allclose(t0, t1, atol=2e-5)
     assert abs(la0 - la1) < 1e-5 and abs(lv0 - lv1) < 1e-5
+
+
+def test_what_fp16_frames_would_cost_vs_code_frames():
+    """BASELINE configs[4] says "fp16 obs encode".  Recorded here: an fp16 frame plane is NOT exact (0.9 -> 0.89990234,
+    0.3 -> 0.30004883; only -0.5 survives), it moves the critic's value by more than the 1e-5 loss tolerance, while the
+    uint8 code plane (TW_F_MATRIX_CODE, half the bytes of fp16) expands to the very same fp32 inputs."""
+    from twoarmy_amd.engine import TwoarmyEngine
+    from twoarmy_amd.soa.agent.PPO import PPO
+    torch.manual_seed(4)
+    eng = TwoarmyEngine(6, 256, 17, seed=SEED)
+    acts = eng.fill_actions(40)
+    of, oc = eng.alloc_outputs(40), eng.alloc_outputs(40, matrix_codes=True)
+    st = eng.get_state()
+    eng.rollout(40, of, actions=acts)
+    eng.set_state(*st)
+    eng.rollout(40, oc, actions=acts)
+    frames = of["matrix"][-4:].permute(1, 0, 2).contiguous()                        # [N, 4, 289] exact fp32 frames
+    assert torch.equal(TwoarmyEngine.decode_matrix(oc["matrix"][-4:]).permute(1, 0, 2), frames)     # codes: exact
+    f16 = frames.half().float()
+    err = (f16 - frames).abs().max().item()
+    assert 9.0e-5 < err < 1.0e-4                                                    # fp16(0.9) is off by 9.8e-5
+    agent = PPO().to("cuda:0")
+    agent.critic.eval()
+    pos = of["pos"][-4:].permute(1, 0, 2).contiguous()
+    goal = torch.tensor([[2.0, 14.0]], device="cuda:0").expand(256, 2)
+    with torch.no_grad():
+        dv = (agent.critic(f16, pos, goal) - agent.critic(frames, pos, goal)).abs().max().item()
+    assert dv > 1e-5, dv                                                            # beyond north_star's loss tolerance
+    eng.close()
