@@ -13,6 +13,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "minigrid_view.h"
 #include "twoarmy.h"
@@ -167,10 +168,12 @@ __global__ __launch_bounds__(64) void mg_gen_obs_kernel(const uint8_t *__restric
 
 // Compile-time view sizes: lane = (env slot e, view column i) -- the same layout the ballot masks of process_vis use --
 // and the lane keeps its whole column (V cells) in registers: no cell goes through LDS, no per-element div / mod.
-// A wave can serve G groups of E = 64 / V envs with the loads of all groups issued before any is used (G times the
-// bytes in flight per wave); measured on 262 144 random 17x17 worlds G = 4 / 2 is 25-35 % SLOWER than G = 1 (89 vs 66 us
-// at V = 7), so G = 1 ships.  Also measured and rejected: staging each (env, plane) span through LDS with 16-byte
-// loads (89 vs 66 us).  V = 7 costs 66 us with or without process_vis; V = 17 went 397 -> 322 us with this kernel.
+// Counters (rocprofv3 --pmc, V = 7): a wave lives ~35 k cycles for ~860 instructions and waits 73 % of that time
+// (SQ_WAIT_ANY / SQ_WAVE_CYCLES) -- the kernel is bound by dependent memory round trips at full occupancy, so the
+// three plane bytes of every cell are loaded unconditionally and up front (a colour / state load gated on the type
+// byte was a third round trip): V = 7 66 -> 56 us on 262 144 random 17x17 worlds.  Measured and rejected: G > 1 env
+// groups per wave (G = 2 / 4: 10-60 % slower at every view size, registers cost occupancy) and staging each
+// (env, plane) span through LDS with 16-byte loads (89 vs 66 us).
 template <int V, int G>
 __global__ __launch_bounds__(64) void mg_gen_obs_cols_kernel(const uint8_t *__restrict__ type, const uint8_t *__restrict__ colour,
                                                              const uint8_t *__restrict__ state, int N, int W, int H,
@@ -198,6 +201,11 @@ __global__ __launch_bounds__(64) void mg_gen_obs_cols_kernel(const uint8_t *__re
     }
     uint32_t cell[G][V], carried[G];
     int ph[G];
+    // Every plane byte of every group is requested before any is used: the three planes unconditionally (a colour /
+    // state load that waits for the type byte is one more dependent HBM round trip, and its branch keeps the groups
+    // from overlapping), out-of-world cells at a clamped, always valid address.
+    uint8_t tb[G][V], cb[G][V], sb[G][V];
+    bool inw[G][V];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         // get_view_exts (minigrid.py:1262-1293) and the number of rotate_left applications
@@ -213,13 +221,21 @@ __global__ __launch_bounds__(64) void mg_gen_obs_cols_kernel(const uint8_t *__re
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             const int x = topx + sx0 + j * dxj, y = topy + sy0 + j * dyj;
-            uint32_t c = WALL_CELL;                                         // Grid.slice: outside the world -> Wall()
-            if (act[g] && x >= 0 && x < W && y >= 0 && y < H) {
-                const size_t o = pbase + (size_t)y * W + x;
-                const uint32_t t = type[o];
-                c = (t <= T_EMPTY) ? EMPTY_CELL : (t | ((uint32_t)colour[o] << 8) | ((state ? (uint32_t)state[o] : 0u) << 16));
-            }
-            cell[g][j] = c;
+            inw[g][j] = act[g] && x >= 0 && x < W && y >= 0 && y < H;
+            const int xc = min(max(x, 0), W - 1), yc = min(max(y, 0), H - 1);
+            const size_t o = pbase + (size_t)yc * W + xc;
+            tb[g][j] = type[o];
+            cb[g][j] = colour[o];
+            sb[g][j] = state ? state[o] : (uint8_t)0;
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const uint32_t t = tb[g][j];
+            const uint32_t c = (t <= T_EMPTY) ? EMPTY_CELL : (t | ((uint32_t)cb[g][j] << 8) | ((uint32_t)sb[g][j] << 16));
+            cell[g][j] = inw[g][j] ? c : WALL_CELL;                       // Grid.slice: outside the world -> Wall()
         }
         carried[g] = EMPTY_CELL;
         if (carrying && carrying[(size_t)n[g] * 3] != 0)
@@ -356,7 +372,7 @@ extern "C" int mg_gen_obs(const uint8_t *type, const uint8_t *colour, const uint
                        image_pitch, vis_mask)
 #define MG_LAUNCH_COLS(VT)                                                                                             \
     do {                                                                                                               \
-        constexpr int GG = 1;   /* env groups per wavefront; 4 (V <= 9) / 2 measured 25-35 % slower: registers, occupancy */ \
+        constexpr int GG = 1;   /* env groups per wavefront; 2 / 4 measured 10-60 % slower at every view size */        \
         const dim3 grid_g((n_envs + E * GG - 1) / (E * GG));                                                           \
         hipLaunchKernelGGL((mg_gen_obs_cols_kernel<VT, GG>), grid_g, block, 0, (hipStream_t)stream, type, colour,      \
                            state, n_envs, width, height, agent_x, agent_y, agent_dir, carrying,                        \
