@@ -73,7 +73,10 @@ def broadcast_parameters(modules, src=0):
         return
     for m in modules:
         for t in list(m.parameters()) + list(m.buffers()):
-            dist.broadcast(t.data, src)
+            buf = t.data.contiguous()               # channels-last conv weights (use_nhwc) are not "contiguous" for c10d
+            dist.broadcast(buf, src)
+            if buf.data_ptr() != t.data.data_ptr():
+                t.data.copy_(buf)
 
 
 def global_adv_norm_(adv, eps=1e-8):

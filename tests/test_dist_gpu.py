@@ -32,9 +32,11 @@ def _worker(rank, world, port, mode, q):
     if mode == "ppo":
         from twoarmy_amd.soa.agent.PPO import PPO
         from twoarmy_amd.soa.ppo_vec import VecPPOTrainer
+        torch.manual_seed(1234 + rank)                         # DIFFERENT replicas: the broadcast must make them equal
         agent = PPO()
         agent.K_epochs = 2
-        agent.to("cuda:0")
+        agent.to("cuda:0").use_nhwc()                          # the entry points' order: to(device), channels-last, broadcast
+        twdist.broadcast_parameters([agent.actor, agent.critic])
         bucket = twdist.GradBucket(list(agent.actor.parameters()) + list(agent.critic.parameters()))
 
         def sync(_p=None):
