@@ -240,13 +240,11 @@ class TwoarmyEngine:
                     truncated=owner.tensor(o.truncated, TN, torch.uint8).view(lead))
 
     def alloc_outputs_tuned(self, T, candidates=6, iters=4, **kw):
-        """alloc_outputs(T) with an HBM placement probe: `candidates` output sets are allocated side by side, a few
-        rollouts are timed into each (HIP events), the fastest set is kept and the others are released.
-
-        Why: the rollout is bound by the store path, and where the driver places the two big output streams in HBM
-        changes the achieved bandwidth by up to 25 % for the very same kernel and buffers of the very same size and
-        alignment (0.179 ... 0.224 ms per launch over 8 allocations in one process, stable per allocation;
-        tools/placement_probe.py).  The env state is restored after probing.  Returns (outputs, probe_ms list)."""
+        """DIAGNOSTIC (round 1's placement probe, kept for tools/placement_probe*.py and `bench.py
+        --placement-candidates`): `candidates` two-stream output sets from torch's allocator are timed with real rollouts
+        and the fastest is kept; the env state is restored.  Not needed any more: alloc_outputs() hands out the engine's
+        record-layout slab, which is equally fast on every allocation.
+        Returns (outputs, probe_ms list)."""
         state = self.get_state()
         acts = self.fill_actions(T)
         sets = [self.alloc_outputs(T, slab=False, **kw) for _ in range(int(candidates))]

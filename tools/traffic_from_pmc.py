@@ -2,7 +2,7 @@
 """HBM traffic per launch of tw_pipe_kernel from two rocprofv3 counter passes (MI355X_MICROARCH.md, HBM section):
 
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py \\
-      --no-cpu-baseline --steps 512 --warmup 128 --placement-candidates 1
+      --no-cpu-baseline --steps 8 --warmup 2
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py ... (same)
   python tools/traffic_from_pmc.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/r01_traffic.json
 
