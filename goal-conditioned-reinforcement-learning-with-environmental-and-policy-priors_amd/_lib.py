@@ -71,6 +71,7 @@ _SIGS = {
     "tw_last_error_message": (C.c_char_p, []),
     "tw_alloc_outputs": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(TwOutputs)]),
     "tw_free_outputs": (C.c_int, [C.POINTER(TwOutputs)]),
+    "tw_abi_sizeof_outputs": (C.c_int, []),
     "tw_time_rollout": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp,
                                   C.POINTER(C.c_float)]),
 }
@@ -136,6 +137,9 @@ def lib():
                         runtimes.add(line.split()[-1])
         except OSError:
             pass
+        if h.tw_abi_sizeof_outputs() != C.sizeof(TwOutputs):
+            raise TwoarmyLibraryError("struct tw_outputs: the library has %d bytes, the ctypes mirror %d"
+                                      % (h.tw_abi_sizeof_outputs(), C.sizeof(TwOutputs)))
         if len(runtimes) > 1:
             raise TwoarmyLibraryError("two HIP runtimes mapped (%s): import torch before loading %s"
                                       % (sorted(runtimes), LIB_PATH))

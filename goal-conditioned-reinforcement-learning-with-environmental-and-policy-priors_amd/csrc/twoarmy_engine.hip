@@ -2083,6 +2083,8 @@ int tw_free_outputs(tw_outputs *out) {
     return rc;
 }
 
+int tw_abi_sizeof_outputs(void) { return (int)sizeof(tw_outputs); }
+
 int tw_n_envs(const tw_engine *e) { return e ? e->n_envs : TW_E_ARG; }
 int tw_view_size(const tw_engine *e) { return e ? e->view : TW_E_ARG; }
 int tw_last_hip_error(void) { return g_last_hip_error; }

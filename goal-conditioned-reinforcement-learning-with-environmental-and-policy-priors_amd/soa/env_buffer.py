@@ -1,8 +1,10 @@
 """Env adapter + replay buffer of the PPO path (reference soa/env_buffer.py).
 
 `Env_transact` keeps the reference's method names and return shapes (matrix_env, data_env,
-env_action, reset, step) on top of the facade env; the state matrix comes from the HIP kernel's fused
-output instead of a Python loop over 289 cells.  `Buffer_gridworld` is the numpy ring buffer with the
+env_action, reset, step) on top of the N = 1 facade env.  `matrix_env` restates the reference's 289-cell Python loop
+as one numpy expression over the facade's type plane and returns the reference's float64 values (valid in any state,
+also right after `reset()`); the vector path (`TwoarmyVecEnv`, `VecPPOTrainer`) takes the same matrix as the HIP
+kernel's fused fp32 output, checked equal in tests/test_stack_gpu.py.  `Buffer_gridworld` is the numpy ring buffer with the
 reference's store() and hindsight relabelling her_func() (env_buffer.py:68-77, 101-143) -- host logic,
 identical index arithmetic, checked against tests/golden/her.npz.
 """

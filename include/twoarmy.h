@@ -180,6 +180,7 @@ typedef struct tw_outputs {
 } tw_outputs;
 int tw_alloc_outputs(tw_engine *e, int T, int flags, tw_outputs *out);
 int tw_free_outputs(tw_outputs *out);
+int tw_abi_sizeof_outputs(void);      /* sizeof(tw_outputs) of the built library: lets a binding check its struct mirror */
 
 /* Time one launch of the engine kernel with hipEvents on `stream` (bench.py roofline leg):
  * runs tw_rollout `iters` times back-to-back and returns the mean kernel time in milliseconds. */
