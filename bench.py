@@ -127,6 +127,8 @@ def build_parser():
     ap.add_argument("--k-epochs", type=int, default=1)
     ap.add_argument("--amp", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--her", action="store_true")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="ppo mode: replay the rollout as one HIP graph (auto: on for <= 512 envs per GPU)")
     ap.add_argument("--nchw", action="store_true", help="ppo mode: literal NCHW nn.Sequential conv stacks (default: channels-last "
                     "+ fused epilogues)")
     ap.add_argument("--predictor", action="store_true", help="ppo mode: PPO + predictor head (configs[4])")
@@ -366,6 +368,7 @@ def run_ppo_mode(args, rank, world, dev, coll):
     eng = TwoarmyEngine(variant, N, 17, device=dev, seed=SEED, env_id0=rank * N)
     tr = VecPPOTrainer(agent, eng, rollout_steps=T, minibatch=args.minibatch, frame_codes=args.matrix_codes)
     tr.time_phases = True
+    tr.use_graph = not args.predictor and (args.graph == "on" or (args.graph == "auto" and N <= 512))
     roll_s, upd_s, her_n = [], [], []
 
     def iteration(timed):
@@ -414,6 +417,7 @@ def run_ppo_mode(args, rank, world, dev, coll):
                    "envs_per_gpu": N, "rollout_s": r, "update_s": u, "rollout_env_steps_per_s_per_gpu": S / r,
                    "update_targets_s": tr.last_update_timing["targets_s"], "update_epoch_s": tr.last_update_timing["epoch_s"],
                    "conv_layout": "nchw (literal nn.Sequential)" if args.nchw else "nhwc + fused upsample/conv1 and conv epilogues",
+                   "rollout_as_hip_graph": bool(tr.use_graph),
                    "her_records_per_iteration": sum(her_n) / max(1, len(her_n)),
                    "parallelism": "env-sharded x%d, one gradient-bucket all-reduce per optimiser step" % world,
                    "collective": coll,

@@ -80,6 +80,7 @@ _f, _i, _u64, _i64 = C.c_float, C.c_int, C.c_uint64, C.c_int64
 _SIGS.update({
     # include/twoarmy_ppo.h
     "ppo_sample": (C.c_int, [_vp, _i, _i, _vp, _u64, _u64, _vp, _vp, _vp]),
+    "ppo_sample_dev": (C.c_int, [_vp, _i, _i, _vp, _u64, _u64, _vp, _vp, _vp, _vp]),
     "ppo_gae": (C.c_int, [_vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ppo_adv_norm": (C.c_int, [_vp, _i64, _f, _vp, _vp]),
     "ppo_loss_fwd_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),

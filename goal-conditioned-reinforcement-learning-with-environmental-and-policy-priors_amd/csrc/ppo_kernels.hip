@@ -30,8 +30,8 @@ __device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t
 // ------------------------------------------------------------------ categorical sample
 template <int A>
 __global__ void ppo_sample_kernel(const float *__restrict__ probs, int B, const float *__restrict__ uniforms,
-                                  uint32_t k0, uint32_t k1, uint64_t offset, int32_t *__restrict__ action,
-                                  float *__restrict__ logp) {
+                                  uint32_t k0, uint32_t k1, uint64_t offset, const uint64_t *__restrict__ offset_dev,
+                                  int32_t *__restrict__ action, float *__restrict__ logp) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     float p[A];
@@ -41,7 +41,7 @@ __global__ void ppo_sample_kernel(const float *__restrict__ probs, int B, const 
     float u;
     if (uniforms) u = uniforms[b];
     else {
-        const uint64_t ctr = (uint64_t)b + offset;
+        const uint64_t ctr = (uint64_t)b + offset + (offset_dev ? *offset_dev : 0ull);
         uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0, c3 = 0x54574F53u;   // 'TWOS'
         philox4x32_10(k0, k1, c0, c1, c2, c3);
         u = (float)(c0 >> 8) * (1.0f / 16777216.0f);       // 24 random bits -> [0, 1)
@@ -570,18 +570,26 @@ extern "C" {
 
 int ppo_sample(const float *probs, int B, int A, const float *uniforms, uint64_t seed, uint64_t offset,
                int32_t *action, float *logp, void *stream) {
+    return ppo_sample_dev(probs, B, A, uniforms, seed, offset, nullptr, action, logp, stream);
+}
+
+int ppo_sample_dev(const float *probs, int B, int A, const float *uniforms, uint64_t seed, uint64_t offset,
+                   const uint64_t *offset_dev, int32_t *action, float *logp, void *stream) {
     if (!probs || !action || !logp || B <= 0) return TW_E_ARG;
     const dim3 grid((B + 255) / 256), block(256);
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     hipStream_t st = (hipStream_t)stream;
+#define PPO_SAMPLE_LAUNCH(AA) \
+    hipLaunchKernelGGL(ppo_sample_kernel<AA>, grid, block, 0, st, probs, B, uniforms, k0, k1, offset, offset_dev, action, logp)
     switch (A) {
-    case 5: hipLaunchKernelGGL(ppo_sample_kernel<5>, grid, block, 0, st, probs, B, uniforms, k0, k1, offset, action, logp); break;
-    case 2: hipLaunchKernelGGL(ppo_sample_kernel<2>, grid, block, 0, st, probs, B, uniforms, k0, k1, offset, action, logp); break;
-    case 3: hipLaunchKernelGGL(ppo_sample_kernel<3>, grid, block, 0, st, probs, B, uniforms, k0, k1, offset, action, logp); break;
-    case 4: hipLaunchKernelGGL(ppo_sample_kernel<4>, grid, block, 0, st, probs, B, uniforms, k0, k1, offset, action, logp); break;
-    case 7: hipLaunchKernelGGL(ppo_sample_kernel<7>, grid, block, 0, st, probs, B, uniforms, k0, k1, offset, action, logp); break;
+    case 5: PPO_SAMPLE_LAUNCH(5); break;
+    case 2: PPO_SAMPLE_LAUNCH(2); break;
+    case 3: PPO_SAMPLE_LAUNCH(3); break;
+    case 4: PPO_SAMPLE_LAUNCH(4); break;
+    case 7: PPO_SAMPLE_LAUNCH(7); break;
     default: return TW_E_ARG;
     }
+#undef PPO_SAMPLE_LAUNCH
     return check_launch();
 }
 

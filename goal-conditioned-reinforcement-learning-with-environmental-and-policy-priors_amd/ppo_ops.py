@@ -20,13 +20,14 @@ def _stream(t):
     return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
-def sample(probs, uniforms=None, seed=0, offset=0):
-    """Categorical(probs).sample() + log_prob (reference soa/agent/PPO.py:86-88) -> (int32[B], float[B])."""
+def sample(probs, uniforms=None, seed=0, offset=0, offset_dev=None):
+    """Categorical(probs).sample() + log_prob (reference soa/agent/PPO.py:86-88) -> (int32[B], float[B]).
+    offset_dev: int64[1] device tensor added to the Philox row counter at run time (graph-captured launches)."""
     B, A = probs.shape
     action = torch.empty(B, dtype=torch.int32, device=probs.device)
     logp = torch.empty(B, dtype=torch.float32, device=probs.device)
-    _lib.check(_lib.lib().ppo_sample(_p(probs, torch.float32), B, A, _p(uniforms, torch.float32), seed, offset,
-                                     _p(action), _p(logp), _stream(probs)), "ppo_sample")
+    _lib.check(_lib.lib().ppo_sample_dev(_p(probs, torch.float32), B, A, _p(uniforms, torch.float32), seed, offset,
+                                         _p(offset_dev, torch.int64), _p(action), _p(logp), _stream(probs)), "ppo_sample")
     return action, logp
 
 

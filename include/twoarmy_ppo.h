@@ -31,6 +31,10 @@ extern "C" {
  *   probs float[B][A] (A <= 8), uniforms float[B]|NULL, action int32[B], logp float[B] */
 int ppo_sample(const float *probs, int B, int A, const float *uniforms, uint64_t seed, uint64_t offset,
                int32_t *action, float *logp, void *stream);
+/* The same with the Philox row counter = row + offset + *offset_dev: a launch recorded in a HIP graph (the whole
+ * rollout of VecPPOTrainer is one) takes its position in the stream from device memory at replay time. */
+int ppo_sample_dev(const float *probs, int B, int A, const float *uniforms, uint64_t seed, uint64_t offset,
+                   const uint64_t *offset_dev, int32_t *action, float *logp, void *stream);
 
 /* delta_t = r_t + gamma * nv_t * cut_t - v_t;  A_t = delta_t + gamma*lambda*cut_t*A_{t+1} (A_T = 0);
  * cut_t = use_done_mask ? 1 - done_t : 1.  Outputs (each nullable): adv = A, target = r + gamma*nv*cut

@@ -369,3 +369,70 @@ def test_what_fp16_frames_would_cost_vs_code_frames():
         dv = (agent.critic(f16, pos, goal) - agent.critic(frames, pos, goal)).abs().max().item()
     assert dv > 1e-5, dv                                                            # beyond north_star's loss tolerance
     eng.close()
+
+
+def _canon_state(state):
+    """Zero record fields that are meaningless in the current state (positions of unspawned patrols, wall offsets before
+    the drop): the sequential and the pipelined kernel keep different leftovers there (tests/test_engine_gpu.py:_canon)."""
+    from twoarmy_amd._lib import FIELDS as Fd
+    ty, co, rec = state
+    rec = rec.copy()
+    rec[rec[:, Fd["O1_VALID"]] == 0, Fd["O1X"]:Fd["O1X"] + 6] = 0
+    rec[rec[:, Fd["O2_VALID"]] == 0, Fd["O2X"]:Fd["O2X"] + 8] = 0
+    rec[rec[:, Fd["PONE"]] == 0, Fd["WALL_I1"]:Fd["WALL_I1"] + 2] = 0
+    return ty, co, rec
+
+
+def test_graph_rollout_is_a_correct_rollout():
+    """VecPPOTrainer.use_graph: the whole rollout (stack gather -> actor -> HIP sampler -> engine step -> age, T times)
+    replayed as ONE HIP graph.  Two runs of the actor are not bit-reproducible (MIOpen's split-K kernels), so the graph
+    rollout is checked for what it must be: (a) the engine outputs are exactly what the recorded actions produce from
+    the state the rollout started in (replayed through one pipelined launch of a second engine); (b) the stored
+    log-probs are the actor's log-probs of the stored actions at the stored states (1e-5); (c) the actions are what
+    the sampler draws from those probabilities at the stream position the device-side offset says (> 99.9 %: a
+    probability that differs in its last bit can move a threshold); (d) age / sample_count bookkeeping."""
+    from twoarmy_amd import ppo_ops
+    from twoarmy_amd.engine import TwoarmyEngine
+    from twoarmy_amd.soa.agent.PPO import PPO
+    from twoarmy_amd.soa.ppo_vec import VecPPOTrainer
+    N, T = 96, 24
+    torch.manual_seed(21)
+    eng = TwoarmyEngine(4, N, 17, seed=SEED)
+    agent = PPO()
+    agent.to(eng.device).use_nhwc()
+    tr = VecPPOTrainer(agent, eng, rollout_steps=T, minibatch=1024)
+    tr.use_graph = True
+    for r in range(4):                                      # eager (warm-up), capture + replay, replay, replay
+        start_state = eng.get_state()
+        start_count = agent.sample_count
+        tr.collect()
+        torch.cuda.synchronize()
+        assert (tr._graph is not None) == (r >= 1)
+        assert agent.sample_count == start_count + T * N
+        # (a) engine outputs
+        eng2 = TwoarmyEngine(4, N, 17, seed=SEED)
+        eng2.set_state(*start_state)
+        out = eng2.alloc_outputs(T)
+        eng2.rollout(T, out, actions=tr.action.contiguous(), autoreset=True, policy_idx=True)
+        torch.cuda.synchronize()
+        assert torch.equal(out["matrix"], tr.frames[4:4 + T]) and torch.equal(out["pos"], tr.pos[4:4 + T])
+        assert torch.equal(out["reward"], tr.reward) and torch.equal(out["terminated"], tr.term)
+        assert torch.equal(out["truncated"], tr.trunc)
+        assert all(np.array_equal(u, v) for u, v in zip(_canon_state(eng.get_state()), _canon_state(eng2.get_state())))
+        eng2.close()
+        # (b), (c) policy side
+        idx = torch.arange(T * N, device=tr.device)
+        s4, p4 = tr._stacks((idx // N).int(), (idx % N).int(), after=False)
+        agent.actor.eval()
+        with torch.no_grad():
+            probs = agent.actor_probs(s4, p4, tr.goal1.expand(T * N, 2).contiguous())
+        q = probs / probs.sum(1, keepdim=True)
+        lp = torch.log(q.gather(1, tr.action.view(-1, 1).long()).clamp(1.1920929e-07, 1 - 1.1920929e-07)).view(T, N)
+        assert torch.allclose(lp, tr.logp, atol=1e-5)
+        a_re, _ = ppo_ops.sample(probs.contiguous(), None, seed=agent.sample_seed, offset=start_count)
+        assert float((a_re.view(T, N) == tr.action).float().mean()) > 0.999
+        # (d)
+        d = ((tr.term | tr.trunc) != 0).cpu().numpy(); age = tr.age.cpu().numpy()
+        assert np.array_equal(age[1:], np.where(d, 0, age[:-1] + 1))
+        tr.carry_over()
+    eng.close()
