@@ -118,6 +118,9 @@ def build_parser():
     ap.add_argument("--placement-candidates", type=int, default=1,
                     help="diagnostic: >1 probes that many torch-allocated output sets at set-up and keeps the fastest "
                          "(the default output slab comes from the engine, tw_alloc_outputs)")
+    ap.add_argument("--slab-check", type=int, default=3,
+                    help="rollout mode: time the kernel into this many freshly allocated engine slabs at set-up and report "
+                         "the values (evidence that placement no longer matters; nothing is selected); 1 = skip")
     ap.add_argument("--torch-outputs", action="store_true",
                     help="diagnostic: outputs from torch's caching allocator instead of the engine's slab")
     ap.add_argument("--matrix-codes", action="store_true",
@@ -256,13 +259,23 @@ def run_engine_mode(args, rank, world, dev, coll):
     # the engine's own Philox stream, HBM-resident; launches cycle over a fixed window of it
     n_act = min(W + K, 64) if rollout else W + K
     actions = eng.fill_actions(n_act * T).view(n_act, T, N)
-    placement_ms = None
+    placement_ms, slab_check_ms = None, None
     if rollout and args.placement_candidates > 1:
         out, placement_ms = eng.alloc_outputs_tuned(T, candidates=args.placement_candidates, matrix_codes=args.matrix_codes)
     elif args.torch_outputs or not rollout:
         out = eng.alloc_outputs(T if rollout else None, matrix_codes=args.matrix_codes, slab=False)
     else:
         out = eng.alloc_outputs(T, matrix_codes=args.matrix_codes)          # engine-owned slab (tw_alloc_outputs)
+        if args.slab_check > 1:
+            # untimed evidence, NOT a selection: the kernel time into a few more freshly allocated slabs; `out` (the
+            # first allocation) is what the timed region uses whatever these say.  The env state is restored.
+            state = eng.get_state()
+            slabs = [out] + [eng.alloc_outputs(T, matrix_codes=args.matrix_codes) for _ in range(args.slab_check - 1)]
+            for s_ in slabs:
+                eng.time_rollout(T, s_, actions=actions[0], iters=2)
+            slab_check_ms = [eng.time_rollout(T, s_, actions=actions[0], iters=4) for s_ in slabs]
+            del slabs
+            eng.set_state(*state)
 
     def run(i_begin, n):
         for i in range(i_begin, i_begin + n):
@@ -310,7 +323,12 @@ def run_engine_mode(args, rank, world, dev, coll):
                    "collective": coll,
                    "output_buffers": "torch caching allocator, two streams" if (args.torch_outputs or placement_ms or not rollout)
                                      else "engine slab (tw_alloc_outputs): %s" % getattr(out["matrix"], "_tw_layout", "?"),
-                   "output_placement_probe_ms": placement_ms},
+                   "output_placement_probe_ms": placement_ms,
+                   "slab_check_ms": None if slab_check_ms is None else {
+                       "what": "untimed set-up: kernel ms per launch into %d freshly allocated engine slabs; no selection, "
+                               "the first one is used by the timed region" % len(slab_check_ms),
+                       "ms": slab_check_ms,
+                       "spread": (max(slab_check_ms) - min(slab_check_ms)) / min(slab_check_ms)}},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "tw_pipe_kernel" if pipelined else "tw_rollout_kernel",
