@@ -198,11 +198,12 @@ class _Conv1Up4(torch.autograd.Function):
     themselves need no gradient)."""
 
     @staticmethod
-    def forward(ctx, frames, w, b):
+    def forward(ctx, frames, w, b, wf):
         B, F, _ = frames.shape
         y = torch.empty((B, w.shape[0], 33, 33), dtype=torch.float32, device=frames.device,
                         memory_format=torch.channels_last)
-        wf = fold_conv1_weights(w)
+        if wf is None:
+            wf = fold_conv1_weights(w)
         fr = frames.contiguous()
         _lib.check(_lib.lib().ppo_conv1_up4_bias_relu(_p(fr, torch.float32), B, F, _p(wf), _p(b.detach().contiguous()),
                                                       C.c_void_p(y.data_ptr()), _stream(y)), "ppo_conv1_up4_bias_relu")
@@ -219,7 +220,7 @@ class _Conv1Up4(torch.autograd.Function):
         gb_part = torch.empty((groups, 4, 64), dtype=torch.float32, device=y.device)
         _lib.check(_lib.lib().ppo_conv1_up4_bwd(_p(fr, torch.float32), B, F, C.c_void_p(gy.data_ptr()), C.c_void_p(y.data_ptr()),
                                                 _p(gw_part), _p(gb_part), _stream(y)), "ppo_conv1_up4_bwd")
-        return None, unfold_conv1_grad(gw_part.sum(0)).to(w.dtype), gb_part.sum((0, 1))
+        return None, unfold_conv1_grad(gw_part.sum(0)).to(w.dtype), gb_part.sum((0, 1)), None
 
 
 def unfold_conv1_grad(gwf):
@@ -234,7 +235,8 @@ def unfold_conv1_grad(gwf):
     return out.permute(3, 2, 0, 1).contiguous()
 
 
-def conv1_up4_bias_relu(frames, weight, bias):
-    """frames [B, F, 289] (F = 4 or 8) -> relu(conv2d(upsample_x4(frames), weight, bias, stride 2)), channels-last."""
+def conv1_up4_bias_relu(frames, weight, bias, folded=None):
+    """frames [B, F, 289] (F = 4 or 8) -> relu(conv2d(upsample_x4(frames), weight, bias, stride 2)), channels-last.
+    folded: fold_conv1_weights(weight) computed by the caller (e.g. once per rollout), or None."""
     assert frames.is_cuda and frames.dtype == torch.float32 and weight.shape[2:] == (4, 4) and weight.shape[0] == 64
-    return _Conv1Up4.apply(frames, weight, bias)
+    return _Conv1Up4.apply(frames, weight, bias, folded)

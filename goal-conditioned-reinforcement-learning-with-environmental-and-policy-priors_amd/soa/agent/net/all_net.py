@@ -68,6 +68,23 @@ class TINet(nn.Module):
         self.upsamplingnearest = nn.UpsamplingNearest2d(scale_factor=4)
         self.apply(reference_init)
 
+    _fold_cache = None
+
+    def _folded_conv1(self, ppo_ops):
+        """fold_conv1_weights(conv1.weight), cached across no-grad forwards while the weights are unchanged (the 128
+        actor forwards of a rollout, the critic passes of the targets).  The key holds the weight tensor's version
+        counter (bumped by every in-place optimiser step) and whether a HIP graph is being captured: a tensor folded
+        under capture lives in that graph's memory and is recomputed by its first step at every replay;
+        `clear_fold_cache` (called around a capture) keeps it from leaking into another graph or into eager code."""
+        if torch.is_grad_enabled():
+            return None                                   # training forward: folded inside the op, every call
+        w = self.cnn_base[0].weight
+        key = (w._version, w.data_ptr(), torch.cuda.is_current_stream_capturing())
+        c = self._fold_cache
+        if c is None or c[0] != key:
+            c = self._fold_cache = (key, ppo_ops.fold_conv1_weights(w))
+        return c[1]
+
     def _convs(self, img, skip_first=False):
         """cnn_base; in channels-last fp32 mode each Conv2d + ReLU pair runs as MIOpen conv + one fused epilogue pass
         (skip_first: `img` already is the first layer's activation)."""
@@ -98,7 +115,7 @@ class TINet(nn.Module):
             # upsample + conv1 + bias + ReLU in one kernel, then MIOpen convs with fused epilogues
             from .... import ppo_ops
             c1 = self.cnn_base[0]
-            x = ppo_ops.conv1_up4_bias_relu(state_matrix, c1.weight, c1.bias)
+            x = ppo_ops.conv1_up4_bias_relu(state_matrix, c1.weight, c1.bias, self._folded_conv1(ppo_ops))
             feat = torch.relu(self.fc0(self._convs(x, skip_first=True)))
         else:
             img = state_matrix.contiguous().view(B, F, GRID, GRID)
@@ -107,6 +124,13 @@ class TINet(nn.Module):
             img = self.upsamplingnearest(img)
             feat = torch.relu(self.fc0(self._convs(img)))
         return torch.relu(self.fc1(torch.cat([feat, coords], dim=1)))
+
+
+def clear_fold_cache(modules):
+    for m in modules:
+        for sub in m.modules():
+            if isinstance(sub, TINet):
+                sub._fold_cache = None
 
 
 def use_nhwc(modules, enable=True):

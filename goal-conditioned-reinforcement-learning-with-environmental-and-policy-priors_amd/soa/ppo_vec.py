@@ -108,7 +108,7 @@ class VecPPOTrainer:
     @torch.no_grad()
     def collect(self, uniforms=None):
         """One rollout.  With `use_graph` (small per-GPU batches, where ~25 launches per step make the host the
-        bottleneck: 0.58 ms per step at 256 envs whatever the GPU does) the whole T-step rollout is captured ONCE
+        bottleneck: 0.5-0.7 ms per step at 256 envs whatever the GPU does) the whole T-step rollout is captured ONCE
         as a HIP graph and replayed: the first rollout runs eagerly (MIOpen searches its kernels then), the second is
         captured, every later one is a single graph launch.  The sampler's stream position is read from device memory
         at replay time, so graph and eager rollouts draw the very same actions."""
@@ -120,10 +120,13 @@ class VecPPOTrainer:
             self._graph_warm = True
         else:
             if self._graph is None:
+                from .agent.net.all_net import clear_fold_cache
                 torch.cuda.synchronize(self.device)
                 g = torch.cuda.CUDAGraph()
+                clear_fold_cache(self.agent.trainable_nets())         # nothing folded eagerly may be read by the graph ...
                 with torch.cuda.graph(g):
                     self._collect_steps(None, offset_dev=self._graph_base)
+                clear_fold_cache(self.agent.trainable_nets())         # ... and nothing folded under capture by eager code
                 self._graph = g
             self._graph_base.fill_(self.agent.sample_count)
             self._graph.replay()

@@ -46,7 +46,7 @@ def build_parser():
                         "nn.Sequential path")
     p.add_argument("--graph_rollout", default="auto", choices=["auto", "on", "off"],
                    help="replay the rollout (actor in the loop) as one HIP graph; auto = on for <= 512 envs per rank "
-                        "(plain PPO agent), where the ~25 launches per step are host-bound (2.2x at 256 envs)")
+                        "(plain PPO agent), where the ~25 launches per step are host-bound (1.7x at 256 envs)")
     p.add_argument("--frame_codes", action="store_true", help="store rollout frames as uint8 codes (4x smaller, exact)")
     p.add_argument("--k_epochs", type=int, default=10)
     p.add_argument("--k_epochs_orientation", type=int, default=50, help="SoA: epochs of the orientation head per update")
