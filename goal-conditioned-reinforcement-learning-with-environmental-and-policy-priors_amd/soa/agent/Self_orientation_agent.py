@@ -141,12 +141,14 @@ class self_orinetation_agent(ppo_predictor):
             self.scheduler_actor.step()
             self.scheduler_critic.step()
 
-    def orientation_step(self, x8, p4, goal, displacement):
-        """One optimiser step of the orientation head: NLL of the realised displacement (+3 -> class), :266-281."""
+    def orientation_step(self, x8, p4, goal, displacement, n_valid=None):
+        """One optimiser step of the orientation head: NLL of the realised displacement (+3 -> class), :266-281.
+        n_valid: only the first n_valid rows are samples, the rest pads the minibatch to a fixed shape (no loss)."""
         p0, p1 = self.orient_probs(x8, p4, goal)
         cls = (displacement + 3).long()
-        loss = (-Categorical(probs=p0).log_prob(cls[:, 0]).view(-1, 1)
-                - Categorical(probs=p1).log_prob(cls[:, 1]).view(-1, 1)).mean()
+        nll = (-Categorical(probs=p0).log_prob(cls[:, 0]).view(-1, 1)
+               - Categorical(probs=p1).log_prob(cls[:, 1]).view(-1, 1))
+        loss = nll.mean() if n_valid is None else nll[:n_valid].sum() / float(n_valid)
         self.optimizer_agent_position_preditor.zero_grad()
         loss.backward()
         if self.grad_sync_orient is not None:

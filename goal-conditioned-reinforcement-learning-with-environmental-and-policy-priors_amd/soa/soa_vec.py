@@ -176,9 +176,21 @@ class VecSoATrainer(VecPPOTrainer):
                     old = idx[idx >= n_rollout] - n_rollout
                     s0, p0 = torch.cat([s0, rep["s0"][old]]), torch.cat([p0, rep["p0"][old]])
                     g2, dp = torch.cat([g2, rep["goal2"][old]]), torch.cat([dp, rep["disp"][old]])
+                n_valid = None
+                if self.fixed_shapes and idx.numel() < self.orient_minibatch:
+                    # partial minibatch: padded to the full shape (or, for a sample set smaller than one minibatch, to
+                    # the next power of two) with masked rows behind the real ones -- the sample count changes every
+                    # update and every new conv batch size costs a MIOpen kernel search
+                    full = self.orient_minibatch if perm.numel() >= self.orient_minibatch else \
+                        max(64, 1 << (idx.numel() - 1).bit_length())
+                    if full > idx.numel():
+                        n_valid = idx.numel()
+                        pad = torch.arange(full - n_valid, device=self.device) % n_valid
+                        s0, p0 = torch.cat([s0, s0[pad]]), torch.cat([p0, p0[pad]])
+                        g2, dp = torch.cat([g2, g2[pad]]), torch.cat([dp, dp[pad]])
                 with torch.no_grad():
                     x8 = ag.policy_input(s0)
-                loss = ag.orientation_step(x8, p0, g2, dp)
+                loss = ag.orientation_step(x8, p0, g2, dp, n_valid)
                 done_steps += 1
             assert done_steps == n_steps or not synced, (done_steps, n_steps)
         if ag.use_lr_decay:
