@@ -56,3 +56,22 @@ def test_record_layout_matches_header():
             name, val = item, val + 1
         got[name[3:]] = val
     assert got == twoarmy_amd._lib.FIELDS
+
+
+def test_ctypes_struct_mirrors_the_header():
+    """struct tw_outputs as gcc lays it out from include/twoarmy.h == the ctypes mirror in _lib.py (size and offsets)."""
+    import ctypes as C
+    import subprocess
+    import tempfile
+    import twoarmy_amd
+    fields = [f for f, _ in twoarmy_amd._lib.TwOutputs._fields_]
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "twoarmy.h"\nint main(void){printf("%zu", sizeof(tw_outputs));' + \
+          "".join('printf(" %%zu", offsetof(tw_outputs, %s));' % f for f in fields) + "return 0;}\n"
+    with tempfile.TemporaryDirectory() as d:
+        c, exe = os.path.join(d, "a.c"), os.path.join(d, "a.out")
+        open(c, "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        vals = [int(v) for v in subprocess.check_output([exe]).split()]
+    T = twoarmy_amd._lib.TwOutputs
+    assert vals[0] == C.sizeof(T)
+    assert vals[1:] == [getattr(T, f).offset for f in fields]
