@@ -94,6 +94,7 @@ _SIGS.update({
     "ppo_age_scan": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "ppo_bias_relu_nhwc": (C.c_int, [_vp, _vp, _i64, _i, _vp]),
     "ppo_conv1_up4_bias_relu": (C.c_int, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "ppo_conv1_up4_bias_relu_c": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ppo_conv1_up4_bwd_groups": (C.c_int, [_i]),
     "ppo_conv1_up4_bwd": (C.c_int, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "ppo_relu_bwd_bias_grad_nhwc_blocks": (C.c_int, [_i64, _i]),

@@ -123,12 +123,13 @@ __global__ __launch_bounds__(256) void ppo_relu_bwd_bias_grad_kernel(const float
 // Folded weights wf[py][px][ty][tx][c][64] (taps that a parity does not have carry zeros) come from the caller.
 // Block = 256 threads = 16 channel quads x 16 pixel slots, one sample per block; per parity phase the thread keeps its
 // 4 taps x F x float4 weights in registers and walks the phase's pixels; x values are LDS broadcasts.
-template <int F>
+template <int F, int CQ>                           // F input channels, CQ = output channels / 4 (16 for TINet, 4 for Net_Encoder)
 __global__ __launch_bounds__(256) void ppo_conv1_up4_kernel(const float *__restrict__ frames, const float4 *__restrict__ wf,
                                                             const float4 *__restrict__ bias, float4 *__restrict__ out, int B) {
     __shared__ float xs[F * 18 * 18];                  // [c][18][18]: row / column 17 = zero pad for the (unused) far taps
+    constexpr int SLOTS = 256 / CQ;
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int cq = tid & 15, slot = tid >> 4;
+    const int cq = tid % CQ, slot = tid / CQ;
     const float *src = frames + (size_t)b * F * 289;
     for (int i = tid; i < F * 324; i += 256) {
         const int c = i / 324, r = i - c * 324, y = r / 18, x = r - y * 18;
@@ -136,15 +137,15 @@ __global__ __launch_bounds__(256) void ppo_conv1_up4_kernel(const float *__restr
     }
     __syncthreads();
     const float4 bv = bias[cq];
-    float4 *dst = out + (size_t)b * 1089 * 16;
+    float4 *dst = out + (size_t)b * 1089 * CQ;
 #pragma unroll 1
     for (int ph = 0; ph < 4; ++ph) {
         const int py = ph >> 1, px = ph & 1;
         float4 w[4 * F];
 #pragma unroll
-        for (int k = 0; k < 4 * F; ++k) w[k] = wf[(ph * 4 * F + k) * 16 + cq];      // [ty][tx][c] -> k = (ty*2+tx)*F + c
+        for (int k = 0; k < 4 * F; ++k) w[k] = wf[(ph * 4 * F + k) * CQ + cq];      // [ty][tx][c] -> k = (ty*2+tx)*F + c
         const int ny = 17 - py, nx = 17 - px;               // output rows / columns of this parity
-        for (int q = slot; q < ny * nx; q += 16) {
+        for (int q = slot; q < ny * nx; q += SLOTS) {
             const int m = q / nx, n = q - m * nx;
             float4 acc = bv;
 #pragma unroll
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256) void ppo_conv1_up4_kernel(const float *__restr
                 }
             }
             acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
-            dst[((2 * m + py) * 33 + 2 * n + px) * 16 + cq] = acc;
+            dst[((2 * m + py) * 33 + 2 * n + px) * CQ + cq] = acc;
         }
     }
 }
@@ -730,18 +731,24 @@ int ppo_relu_bwd_bias_grad_nhwc(const float *gy, const float *y, float *gx, floa
 
 int ppo_conv1_up4_bias_relu(const float *frames, int B, int F, const float *folded_w, const float *bias, float *out,
                             void *stream) {
+    return ppo_conv1_up4_bias_relu_c(frames, B, F, 64, folded_w, bias, out, stream);
+}
+
+int ppo_conv1_up4_bias_relu_c(const float *frames, int B, int F, int C_out, const float *folded_w, const float *bias,
+                              float *out, void *stream) {
     if (!frames || !folded_w || !bias || !out || B <= 0 || ((uintptr_t)out & 15u) || ((uintptr_t)folded_w & 15u) ||
         ((uintptr_t)bias & 15u))
         return TW_E_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (F == 4)
-        hipLaunchKernelGGL(ppo_conv1_up4_kernel<4>, dim3(B), dim3(256), 0, st, frames, reinterpret_cast<const float4 *>(folded_w),
-                           reinterpret_cast<const float4 *>(bias), reinterpret_cast<float4 *>(out), B);
-    else if (F == 8)
-        hipLaunchKernelGGL(ppo_conv1_up4_kernel<8>, dim3(B), dim3(256), 0, st, frames, reinterpret_cast<const float4 *>(folded_w),
-                           reinterpret_cast<const float4 *>(bias), reinterpret_cast<float4 *>(out), B);
-    else
-        return TW_E_ARG;
+#define PPO_CONV1_LAUNCH(FF, CQQ)                                                                                        \
+    hipLaunchKernelGGL((ppo_conv1_up4_kernel<FF, CQQ>), dim3(B), dim3(256), 0, st, frames,                               \
+                       reinterpret_cast<const float4 *>(folded_w), reinterpret_cast<const float4 *>(bias),               \
+                       reinterpret_cast<float4 *>(out), B)
+    if (F == 4 && C_out == 64) PPO_CONV1_LAUNCH(4, 16);
+    else if (F == 8 && C_out == 64) PPO_CONV1_LAUNCH(8, 16);
+    else if (F == 1 && C_out == 16) PPO_CONV1_LAUNCH(1, 4);
+    else return TW_E_ARG;
+#undef PPO_CONV1_LAUNCH
     return check_launch();
 }
 

@@ -192,6 +192,20 @@ def fold_conv1_weights(w):
     return cols.permute(0, 1, 4, 5, 3, 2).contiguous()
 
 
+@torch.no_grad()
+def conv1_up4_bias_relu_infer(frames, weight, bias):
+    """Inference-only fused layer for any supported (F, C_out) (include/twoarmy_ppo.h: ppo_conv1_up4_bias_relu_c):
+    frames [B, F, 289] -> relu(conv2d(upsample_x4(frames), weight, bias, stride 2)) as a channels-last [B, C, 33, 33]."""
+    B, F, _ = frames.shape
+    Cout = weight.shape[0]
+    y = torch.empty((B, Cout, 33, 33), dtype=torch.float32, device=frames.device, memory_format=torch.channels_last)
+    wf = fold_conv1_weights(weight)
+    _lib.check(_lib.lib().ppo_conv1_up4_bias_relu_c(_p(frames.contiguous(), torch.float32), B, F, Cout, _p(wf),
+                                                    _p(bias.contiguous(), torch.float32), C.c_void_p(y.data_ptr()),
+                                                    _stream(y)), "ppo_conv1_up4_bias_relu_c")
+    return y
+
+
 class _Conv1Up4(torch.autograd.Function):
     """relu(conv1(upsample_x4(frames)) + b) in one kernel (ppo_conv1_up4_bias_relu); backward in one kernel too
     (ppo_conv1_up4_bwd: ReLU mask, folded weight gradient and bias gradient from one read of gy and y; the frames

@@ -108,12 +108,13 @@ class PPO:
         return self._run(self.critic, x, p, g)
 
     @torch.no_grad()
-    def act_batch(self, frames4, pos4, goal, uniforms=None, offset_dev=None, offset_add=0):
+    def act_batch(self, frames4, pos4, goal, uniforms=None, offset_dev=None, offset_add=0, x=None):
         """frames4 [B,4,289], pos4 [B,4,2], goal [B,2] (device) -> (action int32[B], logp float[B]).
         offset_dev (int64[1] device tensor): the sampler's stream position is *offset_dev + offset_add instead of
-        self.sample_count -- for launches recorded in a HIP graph, whose position must live in device memory."""
+        self.sample_count -- for launches recorded in a HIP graph, whose position must live in device memory.
+        x: policy_input(frames4) when the caller has already computed it."""
         self.actor.eval()
-        probs = self.actor_probs(self.policy_input(frames4), pos4, goal)
+        probs = self.actor_probs(self.policy_input(frames4) if x is None else x, pos4, goal)
         if offset_dev is not None:
             return ppo_ops.sample(probs, uniforms, seed=self.sample_seed, offset=int(offset_add), offset_dev=offset_dev)
         a, logp = ppo_ops.sample(probs, uniforms, seed=self.sample_seed, offset=self.sample_count)

@@ -16,6 +16,7 @@ class ppo_predictor(PPO):
         self.encoder = Net_Encoder()
         self.decoder = Net_Decoder()
         self.predictor = LSTM()
+        self.pred_chunk = 4096                     # samples per pass of the frozen encoder -> LSTM -> decoder
         self.optimizer_actor = torch.optim.Adam(self.actor.parameters(), lr=self.lr, eps=1e-5)
         self.optimizer_critic = torch.optim.Adam(self.critic.parameters(), lr=self.lr, eps=1e-5)
         self.scheduler_actor = torch.optim.lr_scheduler.StepLR(self.optimizer_actor, self.lr_step_size, self.lr_gamma)
@@ -30,14 +31,32 @@ class ppo_predictor(PPO):
     def pred_states(self, state_matrix):
         """(B,4,289) -> predicted next 4 frames (B,4,289) (+ upsampled inputs, full-res predictions)."""
         self.encoder.eval(); self.decoder.eval(); self.predictor.eval()
-        z_c, z_up = self.encoder(state_matrix.reshape(-1, 1, 289))
-        z_pred, _ = self.predictor(z_c.view(-1, 4, 64, 4, 4))
-        frames, full = self.decoder(z_pred[:, 3:7])
-        return frames, z_up, full
+        B = state_matrix.shape[0]
+        if B <= self.pred_chunk:
+            z_c, z_up = self.encoder(state_matrix.reshape(-1, 1, 289))
+            z_pred, _ = self.predictor(z_c.view(-1, 4, 64, 4, 4))
+            frames, full = self.decoder(z_pred[:, 3:7])
+            return frames, z_up, full
+        # the frozen world model in slices: MIOpen's RNN rejects the 3 x 1024 LSTM at 32 768 sequences
+        # (miopenStatusBadParm), and nothing here carries a gradient or a batch statistic
+        parts = [self.pred_states(state_matrix[i:i + self.pred_chunk]) for i in range(0, B, self.pred_chunk)]
+        return tuple(torch.cat([p[k] for p in parts]) for k in range(3))
+
+    @torch.no_grad()
+    def pred_frames(self, state_matrix):
+        """The predicted next 4 frames only (what policy_input needs): the world model without materialising the
+        upsampled inputs, in slices of pred_chunk samples."""
+        self.encoder.eval(); self.decoder.eval(); self.predictor.eval()
+        out = []
+        for i in range(0, state_matrix.shape[0], self.pred_chunk):
+            z_c, _ = self.encoder(state_matrix[i:i + self.pred_chunk].reshape(-1, 1, 289), need_upsampled=False)
+            z_pred, _ = self.predictor(z_c.view(-1, 4, 64, 4, 4))
+            out.append(self.decoder(z_pred[:, 3:7])[0])
+        return out[0] if len(out) == 1 else torch.cat(out)
 
     def policy_input(self, frames4):
         """What actor / critic consume: the 4 real frames followed by the 4 predicted ones (8 channels)."""
-        return torch.cat([frames4, self.pred_states(frames4)[0].detach()], dim=1)
+        return torch.cat([frames4, self.pred_frames(frames4).detach()], dim=1)
 
     def load_world_model(self, checkpoint):
         """Checkpoint dict with the reference's keys 'model_encoder', 'model_decoder', 'model_predictor'

@@ -254,11 +254,42 @@ class Net_Encoder(nn.Module):
         self.upsamplingnearest = nn.UpsamplingNearest2d(scale_factor=4)
         self.device = None                          # kept for attribute compatibility; tensors stay where they are
 
-    def forward(self, state_matrix):
+    def forward(self, state_matrix, need_upsampled=True):
         B, T, _ = state_matrix.shape
+        if not need_upsampled and state_matrix.is_cuda and state_matrix.dtype == torch.float32 and \
+                not self.training and not torch.is_grad_enabled():
+            return self._forward_fused(state_matrix).view(-1, T, 64, 4, 4), None
         up = self.upsamplingnearest(state_matrix.reshape(-1, 1, GRID, GRID)).float()
         z = self.cnn_base(up)
         return z.view(-1, T, 64, 4, 4), up.view(-1, T, 1, 4 * GRID, 4 * GRID)
+
+    def _forward_fused(self, state_matrix):
+        """Inference path (eval + no_grad, PPO_Predictor.py:72-83): the first conv sees ONE channel of a x4-upsampled
+        17x17 frame -- MIOpen's kernels for that shape took 9.6 ms of the world model's 19.5 ms at 2048 envs.  Here it is
+        the parity-folded 2x2-tap conv of the 17x17 frame (ppo_conv1_up4_bias_relu_c, as TINet's first layer) with the
+        eval-mode BatchNorm folded into its weights and bias and the ReLU applied before its only store; layers 2-3
+        follow on the channels-last activation."""
+        from .... import ppo_ops
+        conv, bn = self.cnn_base[0], self.cnn_base[1]
+        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        w = conv.weight * scale.view(-1, 1, 1, 1)
+        b = (conv.bias - bn.running_mean) * scale + bn.bias
+        x = ppo_ops.conv1_up4_bias_relu_infer(state_matrix.reshape(-1, 1, CELLS), w, b)     # [N, 16, 33, 33] channels-last
+        # layers 2 (16 -> 16, k5, s4) and 3 (16 -> 64, k2, s2), each with its BatchNorm folded in: MIOpen's kernels for
+        # these shapes took ~5 ms per 8192 frames; as a strided-view im2col + ONE GEMM each they are < 1 ms
+        N = x.shape[0]
+        a = x.permute(0, 2, 3, 1)                                            # [N, 33, 33, 16] view of the same memory
+        for conv, bn in ((self.cnn_base[3], self.cnn_base[4]), (self.cnn_base[6], self.cnn_base[7])):
+            k, st = conv.kernel_size[0], conv.stride[0]
+            Hh, Ci = a.shape[1], a.shape[3]
+            Ho = (Hh - k) // st + 1
+            sN, sH, sW, sC = a.stride()
+            patches = a.as_strided((N, Ho, Ho, k, k, Ci), (sN, st * sH, st * sW, sH, sW, sC)).reshape(N * Ho * Ho, k * k * Ci)
+            scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+            wmat = (conv.weight * scale.view(-1, 1, 1, 1)).permute(2, 3, 1, 0).reshape(k * k * Ci, -1)   # [(ky, kx, c), out]
+            bvec = (conv.bias - bn.running_mean) * scale + bn.bias
+            a = torch.relu(torch.addmm(bvec, patches, wmat)).view(N, Ho, Ho, -1)                      # channels-last again
+        return a.permute(0, 3, 1, 2)                                         # [N, 64, 4, 4] (logical NCHW, like the modules)
 
 
 class LSTM(nn.Module):
@@ -275,6 +306,9 @@ class LSTM(nn.Module):
     def forward(self, z_content):
         B, T, D, W, H = z_content.shape
         z_in = z_content.reshape(B, T, D * W * H)
+        if z_in.is_cuda and not torch.is_grad_enabled() and not self.training:
+            z = self._forward_gemm(z_in)
+            return z.reshape(B, self.nt - 1, D, W, H), z_in
         zeros = z_in.new_zeros(3, B, 1024)
         z_past, state = self.recurrent_model(z_in, (zeros, zeros.clone()))
         z_n = z_past[:, -1:].contiguous()
@@ -284,6 +318,46 @@ class LSTM(nn.Module):
             future.append(z_n)
         z = torch.cat([z_past] + future, dim=1)
         return z.reshape(B, self.nt - 1, D, W, H), z_in
+
+    def _forward_gemm(self, z_in):
+        """Inference path of the frozen world model (eval + no_grad, the only way PPO_Predictor.py:72-83 runs it): the
+        same LSTM cell arithmetic (i, f, g, o gates; c' = f c + i g; h' = o tanh c') as explicit hipBLASLt GEMMs --
+        the input projections of the T known steps of a layer in ONE GEMM (M = B T), the recurrent ones per step --
+        plus pointwise ops, instead of MIOpen's RNN (34 TFLOP/s at B = 2048; these 1024 x 4096 GEMMs run ~3x that).
+        Then nt - 4 - 1 autoregressive steps through the three layers.  -> [B, T + 3, 1024]"""
+        m = self.recurrent_model
+        B, T, _ = z_in.shape
+        L = m.num_layers
+        Wih = [getattr(m, "weight_ih_l%d" % k) for k in range(L)]
+        Whh = [getattr(m, "weight_hh_l%d" % k) for k in range(L)]
+        bias = [getattr(m, "bias_ih_l%d" % k) + getattr(m, "bias_hh_l%d" % k) for k in range(L)]
+
+        def cell(gates, c):
+            i, f, g, o = gates.chunk(4, dim=1)
+            c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+            return torch.sigmoid(o) * torch.tanh(c), c
+
+        h = [z_in.new_zeros(B, 1024) for _ in range(L)]
+        c = [z_in.new_zeros(B, 1024) for _ in range(L)]
+        x = z_in                                                    # [B, T, 1024]: the layer's inputs for the known steps
+        for k in range(L):
+            xin = torch.addmm(bias[k], x.reshape(B * T, -1), Wih[k].t()).view(B, T, -1)      # one GEMM for all T steps
+            outs = []
+            for t in range(T):
+                h[k], c[k] = cell(torch.addmm(xin[:, t], h[k], Whh[k].t()), c[k])
+                outs.append(h[k])
+            x = torch.stack(outs, dim=1)
+        seq = [x]
+        z_n = x[:, -1]
+        for _ in range(self.nt - 4 - 1):
+            inp = z_n
+            for k in range(L):
+                gates = torch.addmm(bias[k], inp, Wih[k].t())
+                h[k], c[k] = cell(torch.addmm(gates, h[k], Whh[k].t()), c[k])
+                inp = h[k]
+            z_n = inp
+            seq.append(z_n.unsqueeze(1))
+        return torch.cat(seq, dim=1)
 
 
 class Net_Decoder(nn.Module):

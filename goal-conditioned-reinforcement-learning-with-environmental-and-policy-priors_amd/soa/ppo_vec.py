@@ -32,6 +32,12 @@ class VecPPOTrainer:
         self.frame_codes = bool(frame_codes)
         self.reuse_next_values = True             # V(s'_t) = V(s_{t+1}) inside an episode (_values_rollout)
         self.fixed_shapes = True                  # pad partial minibatches / value chunks to the full size (masked rows)
+        # agents whose policy input holds frames PREDICTED by a frozen world model (ppo_predictor): those frames depend only
+        # on the acting state's 4-frame stack, so the rollout's own evaluation is kept ([T][N][4][289], 2.4 GB at
+        # 4096 x 128) and the target pass and every epoch reuse it instead of re-running the encoder -> LSTM -> decoder
+        # (7x the flops of the policy itself) on the same states
+        self.cache_predictions = hasattr(agent, "pred_states")
+        self.pred_frames, self._pred_valid = None, False
         self.use_graph = False                    # collect(): replay the rollout as one HIP graph (see collect)
         self._graph, self._graph_warm = None, False
         self._graph_base = torch.zeros(1, dtype=torch.int64, device=d)
@@ -94,16 +100,32 @@ class VecPPOTrainer:
         T, N = self.T, self.N
         step_out = [{"obs": None, "matrix": self.frames[t + 4], "pos": self.pos[t + 4], "reward": self.reward[t],
                      "terminated": self.term[t], "truncated": self.trunc[t]} for t in range(T)]
+        if self.cache_predictions and self.pred_frames is None:
+            self.pred_frames = torch.empty((T, N, 4, 289), dtype=torch.float32, device=self.device)
+        self._pred_valid = False
         for t in range(T):
             s4, p4 = ppo_ops.gather_stack(self.frames, self.pos, self.k_rows[t], self.n_all, self.age[t], self.init_frame,
                                           self.init_pos)
-            if offset_dev is None:
+            if self.cache_predictions:
+                x = self.agent.policy_input(s4)
+                self.pred_frames[t] = x[:, 4:]
+                a, logp = self.agent.act_batch(s4, p4, self.goal, None if uniforms is None else uniforms[t], x=x)
+            elif offset_dev is None:
                 a, logp = self.agent.act_batch(s4, p4, self.goal, None if uniforms is None else uniforms[t])
             else:
                 a, logp = self.agent.act_batch(s4, p4, self.goal, None, offset_dev=offset_dev, offset_add=t * N)
             self.action[t], self.logp[t] = a, logp
             self.engine.step(a, step_out[t], autoreset=True, policy_idx=True)
             torch.where((self.term[t] | self.trunc[t]) != 0, self._zero_age, self.age[t] + 1, out=self.age[t + 1])
+        self._pred_valid = self.cache_predictions
+
+    def _policy_x(self, t_idx, n_idx, after):
+        """(network input, positions) of samples (t, n): 4-frame stacks run through agent.policy_input, with the world
+        model's predicted frames taken from the rollout's cache for acting states."""
+        s, p = self._stacks(t_idx, n_idx, after=after)
+        if self._pred_valid and not after:
+            return torch.cat([s, self.pred_frames[t_idx.long(), n_idx.long()]], dim=1), p
+        return self.agent.policy_input(s), p
 
     @torch.no_grad()
     def collect(self, uniforms=None):
@@ -113,7 +135,7 @@ class VecPPOTrainer:
         captured, every later one is a single graph launch.  The sampler's stream position is read from device memory
         at replay time, so graph and eager rollouts draw the very same actions."""
         T, N = self.T, self.N
-        if not (self.use_graph and uniforms is None):
+        if not (self.use_graph and uniforms is None and not self.cache_predictions):
             self._collect_steps(uniforms)
         elif not self._graph_warm:
             self._collect_steps(None)
@@ -207,8 +229,8 @@ class VecPPOTrainer:
             n_real = sl.numel()
             if self.fixed_shapes and n_real < C:
                 sl = torch.cat([sl, sl[torch.arange(C - n_real, device=self.device) % n_real]])   # pad: one conv batch size
-            s, p = self._stacks(t_idx[sl], n_idx[sl], after=after)
-            out = self.agent.critic_value(self.agent.policy_input(s), p, self.goal_input(goal[sl], after)).view(-1)
+            x, p = self._policy_x(t_idx[sl], n_idx[sl], after)
+            out = self.agent.critic_value(x, p, self.goal_input(goal[sl], after)).view(-1)
             v[i:i + n_real] = out[:n_real]
         return v
 
@@ -305,9 +327,10 @@ class VecPPOTrainer:
                     # gradients; a new batch size would cost a MIOpen kernel search -- seconds -- every update)
                     n_valid = idx.numel()
                     idx = torch.cat([idx, idx[torch.arange(self.minibatch - n_valid, device=self.device) % n_valid]])
-                s0, p0 = self._stacks(smp_t[idx], smp_n[idx], after=False)
-                la, lv = ag.minibatch_step(s0, p0, self.goal_input(smp_goal[idx], False), act[idx],
-                                           logp[idx].view(-1, 1), adv[idx].view(-1, 1), target[idx].view(-1, 1), n_valid)
+                with torch.no_grad():
+                    x0, p0 = self._policy_x(smp_t[idx], smp_n[idx], False)
+                la, lv = ag.minibatch_step_x(x0, p0, self.goal_input(smp_goal[idx], False), act[idx],
+                                             logp[idx].view(-1, 1), adv[idx].view(-1, 1), target[idx].view(-1, 1), n_valid)
                 done_steps += 1
             assert done_steps == n_steps or not synced, (done_steps, n_steps)
         if ag.use_lr_decay:

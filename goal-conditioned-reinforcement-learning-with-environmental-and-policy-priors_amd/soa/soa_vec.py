@@ -40,6 +40,7 @@ class VecSoATrainer(VecPPOTrainer):
         """uniforms: f32[T+1, N, 3] or None (row T feeds the orientation draw of the state after the last step)."""
         T, N = self.T, self.N
         ag = self.agent
+        self._pred_valid = False                         # this rollout loop does not fill the prediction cache
         for t in range(T + 1):
             k = torch.full((N,), t + 3, dtype=torch.int32, device=self.device)
             s4, p4 = ppo_ops.gather_stack(self.frames, self.pos, k, self.n_all, self.age[t], self.init_frame, self.init_pos)

@@ -135,6 +135,11 @@ int ppo_relu_bwd_bias_grad_nhwc(const float *gy, const float *y, float *gx, floa
  * out float[B][33][33][64] (channels-last).  Same value as the literal layer up to the summation order. */
 int ppo_conv1_up4_bias_relu(const float *frames, int B, int F, const float *folded_w, const float *bias, float *out,
                             void *stream);
+/* The same layer shape with C_out output channels: (F, C_out) = (4, 64) / (8, 64) TINet, (1, 16) the world model's
+ * Net_Encoder (all_net.py:7-50), whose eval-mode BatchNorm the caller folds into folded_w / bias.
+ * folded_w float[2][2][2][2][F][C_out], out float[B][33][33][C_out]. */
+int ppo_conv1_up4_bias_relu_c(const float *frames, int B, int F, int C_out, const float *folded_w, const float *bias,
+                              float *out, void *stream);
 
 /* Backward of ppo_conv1_up4_bias_relu w.r.t. the folded weights and the bias (the frames carry no gradient):
  *   g = gy * (y > 0);  gw_partial[group][2][2][2][2][F][64] / gb_partial[group][4][64] = per-block partial sums over the

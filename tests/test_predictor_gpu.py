@@ -114,3 +114,40 @@ def test_offline_world_model_training_matches_reference_on_gpu():
     1e-5 claim is carried by test_offline_losses_and_gradients_on_gpu_equal_cpu_at_identical_weights."""
     torch.backends.cudnn.deterministic = True
     check_offline_world_model_training(DEV, 5e-4, atol_first=1e-5, atol_pre=5e-3)
+
+
+def test_lstm_gemm_inference_path_equals_the_miopen_rnn():
+    """all_net.LSTM._forward_gemm (the frozen world model as explicit GEMMs + pointwise cell ops, used under eval +
+    no_grad on the GPU) == the nn.LSTM module's own forward (MIOpen RNN) within 1e-5."""
+    from twoarmy_amd.soa.agent.net.all_net import LSTM
+    torch.manual_seed(3)
+    m = LSTM().to(DEV).eval()
+    z = torch.randn(37, 4, 64, 4, 4, device=DEV) * 0.5
+    with torch.no_grad():
+        fast, _ = m(z)
+    with torch.enable_grad():                                   # grad mode selects the module path
+        ref, _ = m(z)
+    assert fast.shape == ref.shape == (37, 7, 64, 4, 4)
+    assert torch.allclose(fast, ref.detach(), atol=1e-5, rtol=1e-5)
+
+
+def test_fused_encoder_path_equals_the_module_path():
+    """ppo_predictor.pred_frames (encoder's first conv fused with the x4 upsampling, eval-mode BatchNorm folded into its
+    weights; LSTM as GEMMs) == pred_states[0] through the literal modules, with BatchNorm statistics that are not the
+    identity."""
+    from test_predictor_cpu import det_weights_v2
+    from twoarmy_amd.soa.agent.PPO_Predictor import ppo_predictor
+    torch.manual_seed(5)
+    agent = ppo_predictor()
+    for i, net in enumerate((agent.encoder, agent.decoder)):
+        net.load_state_dict(det_weights_v2(net, 41 + i))
+    agent.to(DEV)
+    s = torch.tensor([0.9, -0.9, -0.5, 0.3], device=DEV)[torch.randint(0, 4, (70, 4, 289), device=DEV)]
+    agent.pred_chunk = 32                                       # also exercises the slicing
+    fast = agent.pred_frames(s)
+    with torch.no_grad():
+        z_c, z_up = agent.encoder(s.reshape(-1, 1, 289))        # literal modules (need_upsampled=True)
+        z_pred, _ = agent.predictor(z_c.view(-1, 4, 64, 4, 4))
+        ref = agent.decoder(z_pred[:, 3:7])[0]
+    assert z_up is not None and fast.shape == ref.shape == (70, 4, 289)
+    assert torch.allclose(fast, ref, atol=2e-5, rtol=2e-5)

@@ -436,3 +436,39 @@ def test_graph_rollout_is_a_correct_rollout():
         assert np.array_equal(age[1:], np.where(d, 0, age[:-1] + 1))
         tr.carry_over()
     eng.close()
+
+
+def test_predicted_frames_cached_in_the_rollout_equal_recomputed_ones():
+    """PPO + predictor head (configs[4]): the frames the frozen world model predicts for an acting state are kept from
+    the rollout and reused by the target pass and the epochs instead of re-running encoder -> LSTM -> decoder on the
+    same stacks.  Targets and update losses with the cache == without it (1e-5: only the batch composition of the
+    world-model passes differs)."""
+    from twoarmy_amd.engine import TwoarmyEngine
+    from twoarmy_amd.soa.agent.PPO_Predictor import ppo_predictor
+    from twoarmy_amd.soa.ppo_vec import VecPPOTrainer
+    N, T = 32, 40
+    res = []
+    for cache in (True, False):
+        torch.manual_seed(17)
+        eng = TwoarmyEngine(4, N, 17, seed=SEED)
+        agent = ppo_predictor()
+        agent.K_epochs = 1
+        tr = VecPPOTrainer(agent, eng, rollout_steps=T, minibatch=512, value_chunk=512)
+        assert tr.cache_predictions
+        tr.cache_predictions = cache
+        g = torch.Generator(device="cpu").manual_seed(9)
+        tr.collect(uniforms=torch.rand(T, N, generator=g).to(tr.device))
+        assert tr._pred_valid == cache
+        adv, target = tr.compute_targets()
+        la, lv = tr.update(permutations=[torch.randperm(T * N, generator=g)])
+        res.append((tr.action.clone(), adv.clone(), target.clone(), float(la), float(lv)))
+        if cache:       # the cache holds what the world model predicts for the acting states' stacks
+            idx = torch.arange(T * N, device=tr.device)
+            s, _ = tr._stacks((idx // N).int(), (idx % N).int(), after=False)
+            want = agent.pred_states(s)[0]
+            assert torch.allclose(tr.pred_frames.view(T * N, 4, 289), want, atol=1e-5)
+        eng.close()
+    a, b = res
+    assert torch.equal(a[0], b[0])
+    assert torch.allclose(a[1], b[1], atol=2e-5) and torch.allclose(a[2], b[2], atol=2e-5)
+    assert abs(a[3] - b[3]) < 1e-5 and abs(a[4] - b[4]) < 1e-5
