@@ -488,7 +488,7 @@ __global__ __launch_bounds__(64) void ppo_her_kernel(const float *__restrict__ p
                                                      const uint8_t *__restrict__ truncated,
                                                      const int32_t *__restrict__ age0, const float *__restrict__ reward,
                                                      const int32_t *__restrict__ choices, uint32_t k0, uint32_t k1,
-                                                     uint32_t env_id0, uint32_t step0, int T, int N, int max_goals,
+                                                     uint32_t env_id0, uint32_t step0, int T, int N, int max_goals, int skip,
                                                      const int64_t *__restrict__ offsets, int32_t *__restrict__ counts,
                                                      int32_t *__restrict__ out_t, int32_t *__restrict__ out_n,
                                                      float *__restrict__ out_goal, float *__restrict__ out_reward,
@@ -516,9 +516,10 @@ __global__ __launch_bounds__(64) void ppo_her_kernel(const float *__restrict__ p
             const bool in = lane < L;
             const size_t row = (size_t)(s0 + (in ? lane : 0)) * N + n;
             const float py = pos[row * 2], px = pos[row * 2 + 1];
-            // np.unique(axis=0): first occurrence of every distinct (y, x), ordered lexicographically by (y, x)
-            bool first = in;
-            for (int j = 0; j < L; ++j) {
+            // np.unique(axis=0): first occurrence of every distinct (y, x), ordered lexicographically by (y, x).
+            // Window records (skip = 4, env_buffer.py:145-280) only offer the states after steps skip, skip+1, ...
+            bool first = in && lane >= skip;
+            for (int j = skip; j < L; ++j) {
                 const float qy = __shfl(py, j), qx = __shfl(px, j);
                 if (j < lane && qy == py && qx == px) first = false;
             }
@@ -549,7 +550,7 @@ __global__ __launch_bounds__(64) void ppo_her_kernel(const float *__restrict__ p
                 const unsigned long long hit = __ballot(first && rank == pick);
                 if (!hit) continue;
                 const int idx = __builtin_ctzll(hit);
-                if (idx == 0) continue;                                  // env_buffer.py:119 `if 0 < index < cap`
+                if (idx == skip) continue;                               // env_buffer.py:119 / :163 `if 0 < index < cap`
                 if (emit && lane <= idx) {
                     const int64_t o = base + lane;
                     out_t[o] = s0 + lane;
@@ -680,18 +681,27 @@ int ppo_gather_stack_u8(const uint8_t *frames, int frame_pitch, const float *pos
     return check_launch();
 }
 
+int ppo_her_relabel_window(const float *pos, const uint8_t *terminated, const uint8_t *truncated, const int32_t *age0,
+                           const float *reward, const int32_t *choices, uint64_t seed, uint32_t env_id0, uint32_t step0,
+                           int T, int N, int max_goals, int skip, const int64_t *offsets, int32_t *counts, int32_t *out_t,
+                           int32_t *out_n, float *out_goal, float *out_reward, uint8_t *out_done, void *stream) {
+    if (!pos || !terminated || !truncated || !age0 || !reward || T <= 0 || N <= 0 || max_goals < 0) return TW_E_ARG;
+    if (max_goals > 4) return TW_E_ARG;                                  // 4 pick columns / one Philox call
+    if (skip < 0 || skip >= HER_MAX_LEN) return TW_E_ARG;
+    if (!offsets && !counts) return TW_E_ARG;
+    if (offsets && (!out_t || !out_n || !out_goal || !out_reward || !out_done)) return TW_E_ARG;
+    hipLaunchKernelGGL(ppo_her_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, pos, terminated, truncated, age0,
+                       reward, choices, (uint32_t)seed, (uint32_t)(seed >> 32), env_id0, step0, T, N, max_goals, skip,
+                       offsets, counts, out_t, out_n, out_goal, out_reward, out_done);
+    return check_launch();
+}
+
 int ppo_her_relabel(const float *pos, const uint8_t *terminated, const uint8_t *truncated, const int32_t *age0,
                     const float *reward, const int32_t *choices, uint64_t seed, uint32_t env_id0, uint32_t step0, int T,
                     int N, int max_goals, const int64_t *offsets, int32_t *counts, int32_t *out_t, int32_t *out_n,
                     float *out_goal, float *out_reward, uint8_t *out_done, void *stream) {
-    if (!pos || !terminated || !truncated || !age0 || !reward || T <= 0 || N <= 0 || max_goals < 0) return TW_E_ARG;
-    if (max_goals > 4) return TW_E_ARG;                                  // 4 pick columns / one Philox call
-    if (!offsets && !counts) return TW_E_ARG;
-    if (offsets && (!out_t || !out_n || !out_goal || !out_reward || !out_done)) return TW_E_ARG;
-    hipLaunchKernelGGL(ppo_her_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, pos, terminated, truncated, age0,
-                       reward, choices, (uint32_t)seed, (uint32_t)(seed >> 32), env_id0, step0, T, N, max_goals, offsets,
-                       counts, out_t, out_n, out_goal, out_reward, out_done);
-    return check_launch();
+    return ppo_her_relabel_window(pos, terminated, truncated, age0, reward, choices, seed, env_id0, step0, T, N, max_goals,
+                                  0, offsets, counts, out_t, out_n, out_goal, out_reward, out_done, stream);
 }
 
 int ppo_age_scan(const uint8_t *terminated, const uint8_t *truncated, const int32_t *age0, int T, int N, int32_t *age,

@@ -110,9 +110,10 @@ def age_scan(terminated, truncated, age0):
     return age
 
 
-def her_relabel(pos, terminated, truncated, age0, reward, choices=None, seed=0, env_id0=0, step0=0, max_goals=4):
-    """Hindsight relabelling of a time-major rollout (ppo_her_relabel, include/twoarmy_ppo.h; reference
-    Buffer_gridworld.her_func, soa/env_buffer.py:101-143).  Returns a dict of relabelled index records
+def her_relabel(pos, terminated, truncated, age0, reward, choices=None, seed=0, env_id0=0, step0=0, max_goals=4, skip=0):
+    """Hindsight relabelling of a time-major rollout (ppo_her_relabel_window, include/twoarmy_ppo.h; reference
+    Buffer_gridworld.her_func, soa/env_buffer.py:101-143; skip = 4: pre_her_func / pre_f_her_func on the 9-frame window
+    records, :145-280).  Returns a dict of relabelled index records
     {t int32[H], n int32[H], goal f32[H,2], reward f32[H], done u8[H]} and the per-env counts."""
     T, N = terminated.shape
     dev = pos.device
@@ -122,9 +123,9 @@ def her_relabel(pos, terminated, truncated, age0, reward, choices=None, seed=0, 
     counts = torch.empty(N, dtype=torch.int32, device=dev)
     args = [_p(pos, torch.float32), _p(terminated.contiguous(), torch.uint8), _p(truncated.contiguous(), torch.uint8),
             _p(age0.contiguous(), torch.int32), _p(reward.contiguous(), torch.float32), _p(choices), int(seed),
-            int(env_id0), int(step0), T, N, int(max_goals)]
-    fn = _lib.lib().ppo_her_relabel
-    _lib.check(fn(*args, None, _p(counts), None, None, None, None, None, _stream(pos)), "ppo_her_relabel")
+            int(env_id0), int(step0), T, N, int(max_goals), int(skip)]
+    fn = _lib.lib().ppo_her_relabel_window
+    _lib.check(fn(*args, None, _p(counts), None, None, None, None, None, _stream(pos)), "ppo_her_relabel_window")
     incl = torch.cumsum(counts.long(), 0)
     H = int(incl[-1])                                   # the one host sync: the record count sizes the outputs
     offsets = (incl - counts.long()).contiguous()
@@ -134,7 +135,7 @@ def her_relabel(pos, terminated, truncated, age0, reward, choices=None, seed=0, 
                counts=counts)
     if H:
         _lib.check(fn(*args, _p(offsets), _p(counts), _p(out["t"]), _p(out["n"]), _p(out["goal"]), _p(out["reward"]),
-                      _p(out["done"]), _stream(pos)), "ppo_her_relabel")
+                      _p(out["done"]), _stream(pos)), "ppo_her_relabel_window")
     return out
 
 

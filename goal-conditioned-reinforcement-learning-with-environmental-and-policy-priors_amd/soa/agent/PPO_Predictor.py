@@ -8,6 +8,11 @@ from .PPO import PPO
 
 
 class ppo_predictor(PPO):
+    # the entry points of this agent store 9-frame windows from the fifth step on (train_ppo_predictor.py:134,
+    # train_SoA.py:164) and relabel them with pre_her_func / pre_f_her_func (env_buffer.py:145-280): goal candidates are
+    # the states after steps 4, 5, ... of an episode.  VecPPOTrainer.relabel passes this to ppo_her_relabel_window.
+    her_window_delay = 4
+
     def __init__(self, log_root=None, use_tensorboard=False):
         super().__init__(log_root=log_root, use_tensorboard=use_tensorboard)
         # same construction order as the reference (PPO_Predictor.py:32-36)

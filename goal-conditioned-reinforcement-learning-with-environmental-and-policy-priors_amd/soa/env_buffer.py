@@ -6,7 +6,11 @@ as one numpy expression over the facade's type plane and returns the reference's
 also right after `reset()`); the vector path (`TwoarmyVecEnv`, `VecPPOTrainer`) takes the same matrix as the HIP
 kernel's fused fp32 output, checked equal in tests/test_stack_gpu.py.  `Buffer_gridworld` is the numpy ring buffer with the
 reference's store() and hindsight relabelling her_func() (env_buffer.py:68-77, 101-143) -- host logic,
-identical index arithmetic, checked against tests/golden/her.npz.
+identical index arithmetic, checked against tests/golden/her.npz -- and the 9-frame window variants of the predictor /
+self-orientation entry points: pre_store(), future_3_position_store(), pre_her_func(), pre_f_her_func()
+(env_buffer.py:79-99, 145-280), checked against tests/golden/window_her.npz.  The vector trainers do not copy windows:
+they keep one frame per step and relabel by index (ppo_her_relabel with `skip` = 4, see VecPPOTrainer.relabel); these
+classes are the N = 1 API and the statement of what the index arithmetic has to equal.
 """
 import numpy as np
 
@@ -16,10 +20,18 @@ class Buffer_gridworld:
         self.name = None
         self.grid_size = None
         self.transition = None
+        self.pre_transition = None
         self.buffer_capacity = 100000
+        self.buffer_pre_capacity = 100000
         self.buffer = []
+        self.pre_buffer = []
+        self.fp_buffer = []
         self.counter = 0
+        self.pre_counter = 0
+        self.fp_counter = 0
         self.full = False
+        self.pre_full = False
+        self.fp_full = False
         self.epo_counter_start = 0
         self.epo_counter_end = 0
 
@@ -30,6 +42,15 @@ class Buffer_gridworld:
                          ("g", np.float32, (2,)), ("r", np.float32, (1,)), ("d", np.float32, (1,)),
                          ("a_logp", np.float32, (1,))])
 
+    @staticmethod
+    def window_dtype(grid_size=17, with_f=False):
+        """9-frame window records of soa/train_ppo_predictor.py:105-108 (with_f: soa/train_SoA.py:113-116): frames and
+        positions of steps i-3 .. i+5 of record i, and action / reward / done / log-prob (/ predicted displacement) of the
+        five transitions i .. i+4; the update reads transition i (slot 0, frames 0..4)."""
+        f = [("s", np.float64, (9, grid_size ** 2)), ("a", np.int64, (5, 1)), ("p", np.float64, (9, 2)),
+             ("g", np.float64, (2,)), ("r", np.float64, (5, 1)), ("d", np.int64, (5, 1)), ("a_logp", np.float64, (5, 1))]
+        return np.dtype(f + ([("f", np.float64, (5, 2))] if with_f else []))
+
     def store(self, transition):
         if self.counter >= self.buffer_capacity:
             self.counter, self.full = 0, True
@@ -38,6 +59,74 @@ class Buffer_gridworld:
         if self.counter == self.buffer_capacity:
             self.counter, self.full = 0, True
         return self.full
+
+    def pre_store(self, transition):
+        """store() for the window records (env_buffer.py:90-99)."""
+        if self.pre_counter >= self.buffer_pre_capacity:
+            self.pre_counter, self.pre_full = 0, True
+        self.pre_buffer[self.pre_counter] = transition
+        self.pre_counter += 1
+        if self.pre_counter == self.buffer_pre_capacity:
+            self.pre_counter, self.pre_full = 0, True
+        return self.pre_full
+
+    def future_3_position_store(self, transition):
+        """Ring of the windows the orientation head trains on (env_buffer.py:79-88; it shares the window capacity)."""
+        if self.fp_counter >= self.buffer_pre_capacity:
+            self.fp_counter, self.fp_full = 0, True
+        self.fp_buffer[self.fp_counter] = transition
+        self.fp_counter += 1
+        if self.fp_counter == self.buffer_pre_capacity:
+            self.fp_counter, self.fp_full = 0, True
+        return self.fp_full
+
+    def _window_her(self, newgoal_size_in, step_fields):
+        """Hindsight relabelling of the window records of the episode [epo_counter_start, pre_counter).  Record i's
+        newest frame (slot 8) is the state after step i + 4, so the candidates are the first visits among THOSE states;
+        a pick `index` appends records 0..index with g := that state, reward 0.9 / done 1 on transition index + 4
+        (slot 4 of record index), and four more windows that slide this transition down to slot 0 with the achieved
+        state repeated behind it -- the same tail the entry points store at a real episode end."""
+        cap = self.buffer_pre_capacity
+        end = self.pre_counter - 1
+        episode = self.pre_buffer[self.epo_counter_start:end + 1].copy()
+        _, first_visit = np.unique(episode["p"][:, 8, 0:2], return_index=True, axis=0)
+        k = min(newgoal_size_in, first_visit.size)
+        if end - self.epo_counter_start + 1 > 0:
+            for index in np.random.choice(first_visit, size=k, replace=False):
+                if not (0 < index < cap):
+                    continue
+                seg = np.empty(index + 5, dtype=episode.dtype)
+                seg[:index + 1] = episode[:index + 1]
+                seg["g"][:index + 1] = episode["p"][index, 8, 0:2]
+                seg["r"][index, 4] = 0.9
+                seg["d"][index, 4] = 1
+                last = seg[index]
+                for j in range(index + 1, index + 5):
+                    seg[j] = seg[j - 1]
+                    for name in ("p", "s"):
+                        seg[name][j] = np.concatenate([seg[name][j - 1][1:], last[name][8:9]])
+                    for name in step_fields:
+                        seg[name][j] = np.concatenate([seg[name][j - 1][1:], last[name][4:5]])
+                n = index + 5
+                if end + 1 + n <= cap:
+                    self.pre_buffer[end + 1:end + 1 + n] = seg
+                    end += n
+                else:                                   # wrap around the ring
+                    over = end + 1 + n - cap
+                    self.pre_buffer[end + 1:cap] = seg[:n - over]
+                    self.pre_buffer[:over] = seg[n - over:]
+                    end = over - 1
+                    self.pre_full = True
+        self.epo_counter_end = end
+        self.pre_counter = end + 1
+
+    def pre_her_func(self, max_steps=50, newgoal_size_in=4):
+        """env_buffer.py:145-209 (predictor entry point)."""
+        self._window_her(newgoal_size_in, ("a", "r", "d", "a_logp"))
+
+    def pre_f_her_func(self, max_steps=50, newgoal_size_in=4):
+        """env_buffer.py:212-280 (self-orientation entry point: the windows also carry the `f` field)."""
+        self._window_her(newgoal_size_in, ("a", "r", "d", "a_logp", "f"))
 
     def her_func(self, max_steps=50, newgoal_size_in=4):
         """Hindsight relabelling of the episode [epo_counter_start, counter): for up to 4 distinct
@@ -101,6 +190,11 @@ class Env_transact:
         state_matrix = self.matrix_env(env)
         state, goal = self.data_env(env)
         return np.tile(state_matrix, (5, 1)), np.tile(state, (5, 1)), goal
+
+    def predata_reset(self, env):
+        """Initial 9-frame window: the reset state nine times (env_buffer.py:430-437)."""
+        state, _ = self.data_env(env)
+        return np.tile(self.matrix_env(env), (9, 1)), np.tile(state, (9, 1))
 
     def step(self, env, window, action, args=None):
         self.runstep += 1

@@ -184,8 +184,13 @@ class VecPPOTrainer:
         Episodes that began in an earlier rollout are relabelled over a window of rollouts long enough to hold any
         episode that ends now (carry_over keeps positions, rewards and done flags of ceil((max_steps-1)/T) earlier
         rollouts); only the records that lie in the current rollout are returned -- the earlier part of such a prefix
-        belongs to samples whose frames are gone."""
+        belongs to samples whose frames are gone.
+
+        Agents trained on 9-frame window records (ppo_predictor, self_orinetation_agent: `her_window_delay` = 4) get
+        pre_her_func / pre_f_her_func (env_buffer.py:145-280) instead: the goal candidates are the states after steps
+        4, 5, ... of the episode (`skip`), see ppo_her_relabel_window in include/twoarmy_ppo.h."""
         T, N = self.T, self.N
+        skip = int(getattr(self.agent, "her_window_delay", 0))
         if self.max_steps > HER_MAX_LEN:
             raise ValueError("hindsight relabelling handles episodes of up to %d steps (max_steps = %d)"
                              % (HER_MAX_LEN, self.max_steps))
@@ -193,7 +198,7 @@ class VecPPOTrainer:
         if not self._hist or choices is not None:
             self.her = ppo_ops.her_relabel(self.pos[4:4 + T], self.term, self.trunc, self.age[0].contiguous(),
                                            self.reward, choices, seed=self.her_seed, env_id0=self.engine.env_id0,
-                                           step0=start, max_goals=max_goals)
+                                           step0=start, max_goals=max_goals, skip=skip)
             return self.her
         hist = list(self._hist)
         back = T * len(hist)
@@ -201,7 +206,8 @@ class VecPPOTrainer:
                                 torch.cat([x[1] for x in hist] + [self.term]),
                                 torch.cat([x[2] for x in hist] + [self.trunc]), hist[0][4],
                                 torch.cat([x[3] for x in hist] + [self.reward]), None,
-                                seed=self.her_seed, env_id0=self.engine.env_id0, step0=start - back, max_goals=max_goals)
+                                seed=self.her_seed, env_id0=self.engine.env_id0, step0=start - back, max_goals=max_goals,
+                                skip=skip)
         keep = h["t"] >= back
         self.her = dict(t=(h["t"][keep] - back).contiguous(), n=h["n"][keep].contiguous(), goal=h["goal"][keep].contiguous(),
                         reward=h["reward"][keep].contiguous(), done=h["done"][keep].contiguous())

@@ -115,6 +115,16 @@ int ppo_her_relabel(const float *pos, const uint8_t *terminated, const uint8_t *
                     const float *reward, const int32_t *choices, uint64_t seed, uint32_t env_id0, uint32_t step0, int T,
                     int N, int max_goals, const int64_t *offsets, int32_t *counts, int32_t *out_t, int32_t *out_n,
                     float *out_goal, float *out_reward, uint8_t *out_done, void *stream);
+/* The same relabelling for the 9-frame WINDOW records of the predictor / self-orientation entry points
+ * (Buffer_gridworld.pre_her_func / pre_f_her_func, soa/env_buffer.py:145-280; windows stored from the fifth step on,
+ * train_ppo_predictor.py:134).  Window record i carries the state after step i + 4 as its newest frame, so with
+ * skip = 4 the first visits are taken among the states after steps skip, skip + 1, ... only, the first of those is
+ * never a goal (`0 < index`), and a pick relabels transitions 0 .. index + skip -- the prefix records plus the four
+ * sliding tail windows the reference appends.  skip = 0 is ppo_her_relabel. */
+int ppo_her_relabel_window(const float *pos, const uint8_t *terminated, const uint8_t *truncated, const int32_t *age0,
+                           const float *reward, const int32_t *choices, uint64_t seed, uint32_t env_id0, uint32_t step0,
+                           int T, int N, int max_goals, int skip, const int64_t *offsets, int32_t *counts, int32_t *out_t,
+                           int32_t *out_n, float *out_goal, float *out_reward, uint8_t *out_done, void *stream);
 
 /* Epilogues of the conv layers of TINet (all_net.py:141-150: Conv2d + ReLU x 4) on channels-last activations
  * float[n_pixels][C] (n_pixels = B * H * W, C % 4 == 0, C <= 256); the conv GEMMs themselves run in MIOpen.

@@ -5,7 +5,7 @@ TEST INFRASTRUCTURE ONLY.  Imports /root/reference through oracle/ref_harness.py
 classes with scripted / seeded inputs and writes small .npz fixtures into tests/golden/.
 Only data (inputs + the reference's outputs) is written; no reference source text is stored.
 
-  python oracle/gen_golden.py [traces] [views] [her] [ppo] [predictor] [occlusion] [mgstep] [soa] [pretrain]     (default: all)
+  python oracle/gen_golden.py [traces] [views] [her] [window_her] [ppo] [predictor] [occlusion] [mgstep] [soa] [pretrain]     (default: all)
 
 The random draws of Twoarmy (np.random.choice calls in twoarmy_v{4,6}.py) are replaced by the
 engine's counter-based Philox words (oracle/philox.py) through ref_harness.patched_choice, so
@@ -441,6 +441,97 @@ def gen_her():
 
 
 # ----------------------------------------------------------------------------- predictor path
+# ----------------------------------------------------------------------------- HER on 9-frame window records
+def collect_window_episode(env_buffer, variant, buf, seed, with_f):
+    """One episode stored the way soa/train_ppo_predictor.py:105-171 (with_f: soa/train_SoA.py:130-183) stores it:
+    9-frame windows delayed by four steps + the four terminal windows, through the reference's own pre_store()."""
+    rs = np.random.RandomState(seed)
+    slots = PhiloxSlots(SEED, 900 + seed)
+    rec = rh.SlotRecorder(slots)
+
+    class Args:
+        server = True
+
+    class Win:
+        def set_caption(self, *_):
+            pass
+
+        def show_img(self, *_):
+            pass
+
+    def push(stack, row):
+        return np.append(np.delete(stack, 0, 0), [row], 0)
+
+    with rh.patched_choice(rec):
+        env = rh.make_env(variant)
+        et = env_buffer.Env_transact()
+        et.reset(env, Win())
+        sm9, st9 = et.predata_reset(env)
+        a5, r5, d5, l5, f5 = np.zeros((5, 1)), np.zeros((5, 1)), np.zeros((5, 1)), np.zeros((5, 1)), np.zeros((5, 2))
+        buf.epo_counter_start = buf.pre_counter
+
+        def store():
+            rec_ = (np.array(sm9, dtype='float32'), np.array(a5, dtype='int64'), np.array(st9, dtype='float32'),
+                    np.array(goal, dtype='float32'), np.array(r5, dtype='float32'), np.array(d5, dtype='int64'),
+                    np.array(l5, dtype='float32'))
+            buf.pre_store(rec_ + ((np.array(f5, dtype='float32'),) if with_f else ()))
+        for t in range(10000):
+            a_idx = int(rs.choice(5, p=(0.1, 0.3, 0.35, 0.1, 0.15)))
+            logp = float(np.log(0.2) - 0.01 * rs.rand())
+            fut = [float(rs.randint(-3, 4)), float(rs.randint(-3, 4))]
+            slots.begin_step(t)
+            _, r, term, trunc, done = et.step(env, None, et.env_action(env, a_idx), Args)
+            state, goal = et.data_env(env)
+            sm = et.matrix_env(env)
+            for k in range(5 if (term or trunc) else 1):           # the step itself + four terminal repeats
+                st9, sm9 = push(st9, state), push(sm9, sm)
+                a5, r5, d5, l5, f5 = push(a5, [a_idx]), push(r5, [r]), push(d5, [done]), push(l5, [logp]), push(f5, fut)
+                if t > 3 or k > 0:
+                    store()
+            if term or trunc:
+                return t + 1
+
+
+def gen_window_her():
+    """Buffer_gridworld.pre_her_func / pre_f_her_func (soa/env_buffer.py:145-280) on real episodes stored as 9-frame
+    window records, incl. ring wrap; picks from the seeded global numpy stream."""
+    env_buffer, _ = rh.soa_modules()
+    out = {}
+    cases = [dict(cap=320, seed=0, pre=0, variant="v6", f=False), dict(cap=320, seed=1, pre=23, variant="v4", f=False),
+             dict(cap=150, seed=2, pre=60, variant="v6", f=False), dict(cap=320, seed=3, pre=5, variant="v4", f=True),
+             dict(cap=140, seed=4, pre=70, variant="v6", f=True), dict(cap=320, seed=5, pre=0, variant="v6", f=True)]
+    for ci, c in enumerate(cases):
+        fields = [('s', np.float64, (9, 289)), ('a', np.int64, (5, 1)), ('p', np.float64, (9, 2)), ('g', np.float64, (2,)),
+                  ('r', np.float64, (5, 1)), ('d', np.int64, (5, 1)), ('a_logp', np.float64, (5, 1))]
+        if c["f"]:
+            fields.append(('f', np.float64, (5, 2)))
+        buf = env_buffer.Buffer_gridworld()
+        buf.grid_size = 17
+        buf.buffer_pre_capacity = c["cap"]
+        buf.pre_transition = np.dtype(fields)
+        buf.pre_buffer = np.zeros(c["cap"], dtype=buf.pre_transition)
+        buf.pre_counter = c["pre"]
+        L = collect_window_episode(env_buffer, c["variant"], buf, 40 + ci, c["f"])
+        before = buf.pre_buffer.copy()
+        cnt_before, full_before = buf.pre_counter, buf.pre_full
+        np.random.seed(c["seed"])
+        (buf.pre_f_her_func if c["f"] else buf.pre_her_func)(max_steps=50, newgoal_size_in=4)
+        for k in buf.pre_transition.names:
+            out["c%d_before_%s" % (ci, k)] = before[k].astype(np.float32) if k == "s" else before[k]
+            out["c%d_after_%s" % (ci, k)] = buf.pre_buffer[k].astype(np.float32) if k == "s" else buf.pre_buffer[k]
+            if k == "s":                            # frames were stored through float32 (pre_store call sites): lossless
+                assert np.array_equal(before[k], before[k].astype(np.float32).astype(np.float64))
+        out["c%d_meta" % ci] = np.array([c["cap"], c["seed"], c["pre"], L, cnt_before, int(full_before), buf.pre_counter,
+                                         int(buf.pre_full), buf.epo_counter_end, int(c["f"])])
+        print("  case %d: episode of %d steps, %d records before, counter %d -> %d%s" %
+              (ci, L, (cnt_before - c["pre"]) % c["cap"], cnt_before, buf.pre_counter, " (wrapped)" if buf.pre_full else ""))
+    out["n_cases"] = np.int32(len(cases))
+    path_out = os.path.join(GOLD, "window_her.npz")
+    np.savez_compressed(path_out, **out)
+    print("window_her: %d cases -> %s (%.1f KB)" % (len(cases), path_out, os.path.getsize(path_out) / 1024))
+
+
+
 def det_weights_v2(module, seed):
     """det_weights that also gives BatchNorm sane running statistics (var > 0) and keeps integer buffers."""
     import torch
@@ -793,7 +884,7 @@ def gen_mgstep():
     print("mgstep: %d cases -> %s (%.1f KB)" % (ncase, path_out, os.path.getsize(path_out) / 1024))
 
 
-STAGES = {"traces": gen_traces, "views": gen_views, "ppo": gen_ppo, "her": gen_her, "predictor": gen_predictor, "occlusion": gen_occlusion, "mgstep": gen_mgstep, "soa": gen_soa, "pretrain": gen_pretrain}
+STAGES = {"traces": gen_traces, "views": gen_views, "ppo": gen_ppo, "her": gen_her, "window_her": gen_window_her, "predictor": gen_predictor, "occlusion": gen_occlusion, "mgstep": gen_mgstep, "soa": gen_soa, "pretrain": gen_pretrain}
 
 
 def main(argv):

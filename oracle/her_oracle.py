@@ -32,9 +32,16 @@ def philox_picks(seed, env_id, t1, U, k):
     return perm[:k]
 
 
-def relabel(pos, terminated, truncated, age0, reward, choices=None, seed=0, env_id0=0, step0=0, max_goals=4):
+def relabel(pos, terminated, truncated, age0, reward, choices=None, seed=0, env_id0=0, step0=0, max_goals=4, skip=0):
     """pos [T,N,2] achieved (y,x) after each step; returns dict(t, n, goal, reward, done, counts) in the order
-    env-major / episode time order / pick order / prefix time order."""
+    env-major / episode time order / pick order / prefix time order.
+
+    skip = 0: her_func on 5-frame records (env_buffer.py:101-143).  skip = 4: pre_her_func / pre_f_her_func on the
+    9-frame window records (env_buffer.py:145-280): record i of an episode is stored four steps late and its newest
+    frame is the state after step i + 4, so the first visits are taken among the states after steps 4, 5, ... only,
+    `0 < index` excludes the first of THOSE, and a pick relabels the transitions 0 .. index + 4 (prefix records
+    0 .. index plus the four sliding tail windows).  The four repeats of the terminal state at the end of the
+    reference's record sequence are never first visits (episodes here are longer than four steps)."""
     T, N = terminated.shape
     done = (np.asarray(terminated) | np.asarray(truncated)) != 0
     ot, on, og, orw, od = [], [], [], [], []
@@ -48,7 +55,9 @@ def relabel(pos, terminated, truncated, age0, reward, choices=None, seed=0, env_
             if s0 < 0 or t1 - s0 + 1 > MAX_LEN:
                 continue
             ep = pos[s0:t1 + 1, n]                                   # the episode's records (env_buffer.py:105-106)
-            fv = first_visit(ep)
+            if ep.shape[0] <= skip:
+                continue
+            fv = first_visit(ep[skip:])
             U = fv.size
             k = min(max_goals, U)                                    # env_buffer.py:109-112
             if choices is None:
@@ -59,8 +68,9 @@ def relabel(pos, terminated, truncated, age0, reward, choices=None, seed=0, env_
                 if not (0 <= pk < U):
                     continue
                 index = int(fv[pk])
-                if not index > 0:                                    # `if 0 < index < cap` (env_buffer.py:119)
+                if not index > 0:                                    # `if 0 < index < cap` (env_buffer.py:119, :163)
                     continue
+                index += skip                                        # window record `index` <-> transition index + 4
                 for i in range(index + 1):
                     ot.append(s0 + i); on.append(n); og.append(ep[index])
                     orw.append(np.float32(0.9) if i == index else reward[s0 + i, n])
