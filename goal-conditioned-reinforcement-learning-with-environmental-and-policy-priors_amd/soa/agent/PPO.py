@@ -188,17 +188,19 @@ class PPO:
         self.update_count += 1
         return action_loss.detach(), value_loss.detach()
 
+    def _unpack(self, buffer, device):
+        """Record array of Buffer_gridworld -> tensors of the transition every record trains on: 5-frame stacks
+        s[n,5,289] / p[n,5,2] (acting state = frames 0..3, next state = frames 1..4), a[n], g[n,2], r[n], old_logp[n,1]."""
+        f32 = lambda k: torch.as_tensor(buffer[k], dtype=torch.float32, device=device)
+        a = torch.as_tensor(buffer["a"], dtype=torch.int64, device=device).view(-1).to(torch.int32)
+        return f32("s"), f32("p"), a, f32("g"), f32("r").view(-1), f32("a_logp").view(-1, 1)
+
     def update(self, buffer, device, i_ep, permutations=None):
         """Reference signature (PPO.py:103-161): `buffer` is the numpy structured array of
         Buffer_gridworld.  `permutations` (optional, [K_epochs][N]) injects the minibatch order;
         by default torch.randperm is drawn per epoch exactly like SubsetRandomSampler does."""
         device = torch.device(device)
-        s = torch.as_tensor(buffer["s"], dtype=torch.float32, device=device)
-        p = torch.as_tensor(buffer["p"], dtype=torch.float32, device=device)
-        a = torch.as_tensor(buffer["a"], dtype=torch.int64, device=device).view(-1).to(torch.int32)
-        g = torch.as_tensor(buffer["g"], dtype=torch.float32, device=device)
-        r = torch.as_tensor(buffer["r"], dtype=torch.float32, device=device).view(-1)
-        old_logp = torch.as_tensor(buffer["a_logp"], dtype=torch.float32, device=device).view(-1, 1)
+        s, p, a, g, r, old_logp = self._unpack(buffer, device)
         n = s.shape[0]
         self.to(device)
         adv, target_v = self.targets(s, p, g, r)

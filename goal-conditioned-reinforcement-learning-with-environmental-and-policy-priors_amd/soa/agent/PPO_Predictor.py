@@ -1,6 +1,10 @@
 """PPO whose actor / critic see the 4 real frames plus 4 frames predicted by a frozen encoder -> LSTM ->
 decoder world model (reference soa/agent/PPO_Predictor.py:72-193).  Only actor and critic train; the
 loss / sampling / advantage math is the same HIP path as PPO (ppo_ops)."""
+import os
+from datetime import datetime
+
+import numpy as np
 import torch
 
 from .net.all_net import (LSTM, Net_Decoder, Net_Encoder, Net_PPO_Predictor_actor, Net_PPO_Predictor_critic)
@@ -62,6 +66,27 @@ class ppo_predictor(PPO):
     def policy_input(self, frames4):
         """What actor / critic consume: the 4 real frames followed by the 4 predicted ones (8 channels)."""
         return torch.cat([frames4, self.pred_frames(frames4).detach()], dim=1)
+
+    def _unpack(self, buffer, device):
+        """9-frame window records (train_ppo_predictor.py:105-107): the update trains on transition 0 of a window --
+        frames 0..4, slot 0 of a / r / a_logp (PPO_Predictor.py:126-155)."""
+        f32 = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32, device=device)
+        a = torch.as_tensor(np.ascontiguousarray(buffer["a"][:, 0, 0]), dtype=torch.int64, device=device).to(torch.int32)
+        return (f32(buffer["s"][:, :5]), f32(buffer["p"][:, :5]), a, f32(buffer["g"]), f32(buffer["r"][:, 0, 0]),
+                f32(buffer["a_logp"][:, 0, 0]).view(-1, 1))
+
+    def save_param(self, i_ep, running_score):
+        """Checkpoint with the reference's keys (PPO_Predictor.py:113-120): actor / critic + the frozen world model.  The
+        reference also stores optimiser states of the world model, which its update never steps; they are omitted."""
+        state = {"model_actor": self.actor.state_dict(), "model_critic": self.critic.state_dict(),
+                 "model_encoder": self.encoder.state_dict(), "model_decoder": self.decoder.state_dict(),
+                 "model_predictor": self.predictor.state_dict(), "optimizer_actor": self.optimizer_actor.state_dict(),
+                 "optimizer_critic": self.optimizer_critic.state_dict(), "epoch": i_ep}
+        os.makedirs(self.filepath, exist_ok=True)
+        path = os.path.join(str(self.filepath), "%s_net_%depoch_%srunning_score%s.pkl"
+                            % (self.name, i_ep, running_score, datetime.now().strftime("%Y_%m_%d_%H_%M_%S")))
+        torch.save(state, path)
+        return path
 
     def load_world_model(self, checkpoint):
         """Checkpoint dict with the reference's keys 'model_encoder', 'model_decoder', 'model_predictor'

@@ -181,6 +181,20 @@ class Env_transact:
         (i, j), (gi, gj) = env.agent_pos, env.goal_pos
         return np.array((j, i), dtype=float), np.array((gj, gi), dtype=float)
 
+    def free_env(self, env):
+        """(agent (y,x), passable span of the ball row, goal (y,x)) and its 10-deep stack (env_buffer.py:336-356; no caller
+        in the reference's scripts -- kept for API completeness).  The span follows the first ball's column."""
+        (i, j), (gi, gj) = env.agent_pos, env.goal_pos
+        bx = env.obstacles[0].cur_pos[0]
+        free = {6: (8, 9, 8, 10), 7: (8, 6, 8, 10)}.get(int(bx), (8, 6, 8, 7))
+        state = np.concatenate((np.array((j, i), dtype=float), np.array(free), np.array((gj, gi), dtype=float)), axis=0)
+        return state, np.tile(state, (10, 1))
+
+    def pre_col(self, env):
+        """Frame + its 8-deep stack (env_buffer.py:358-362; unused by the reference's scripts)."""
+        m = self.matrix_env(env)
+        return m, np.tile(m, (8, 1))
+
     def env_action(self, env, action_agent):
         a = env.actions
         return {0: a.left, 1: a.right, 2: a.up, 3: a.down, 4: a.done}.get(action_agent)

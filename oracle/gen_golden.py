@@ -5,7 +5,7 @@ TEST INFRASTRUCTURE ONLY.  Imports /root/reference through oracle/ref_harness.py
 classes with scripted / seeded inputs and writes small .npz fixtures into tests/golden/.
 Only data (inputs + the reference's outputs) is written; no reference source text is stored.
 
-  python oracle/gen_golden.py [traces] [views] [her] [window_her] [ppo] [predictor] [occlusion] [mgstep] [soa] [pretrain]     (default: all)
+  python oracle/gen_golden.py [traces] [views] [her] [window_her] [ppo] [predictor] [predictor_update] [occlusion] [mgstep] [soa] [pretrain]     (default: all)
 
 The random draws of Twoarmy (np.random.choice calls in twoarmy_v{4,6}.py) are replaced by the
 engine's counter-based Philox words (oracle/philox.py) through ref_harness.patched_choice, so
@@ -598,6 +598,58 @@ def gen_predictor():
 
 
 
+def gen_predictor_update():
+    """soa/agent/PPO_Predictor.py:123-193 ppo_predictor.update on 9-frame window records (train_ppo_predictor.py:105-107)
+    with seeded weights: the per-minibatch losses, and the minibatch order it drew."""
+    import torch
+    env_buffer, ppo_mod = rh.soa_modules()
+    from agent import PPO_Predictor as pp_mod
+    pp_mod.heatmap = lambda *a, **k: None
+    out = {}
+    torch.manual_seed(SEED)
+    agent = pp_mod.ppo_predictor()
+    for i, net in enumerate((agent.actor, agent.critic, agent.encoder, agent.decoder)):
+        net.load_state_dict(det_weights_v2(net, 11 + i))
+    lstm_sd = {}
+    for k, (name, prm) in enumerate(agent.predictor.state_dict().items()):
+        n = prm.numel()
+        lstm_sd[name] = torch.tensor((0.03 * np.sin(0.37 * np.arange(n, dtype=np.float64) + 1.3 * k)).reshape(tuple(prm.shape)),
+                                     dtype=prm.dtype)
+    agent.predictor.load_state_dict(lstm_sd)
+    dev = torch.device("cpu")
+    agent.encoder.device = agent.predictor.device = dev
+    # window records of a real episode, stored and relabelled by the reference's own buffer code
+    buf = env_buffer.Buffer_gridworld()
+    buf.grid_size = 17
+    buf.buffer_pre_capacity = 200
+    buf.pre_transition = np.dtype([('s', np.float64, (9, 289)), ('a', np.int64, (5, 1)), ('p', np.float64, (9, 2)),
+                                   ('g', np.float64, (2,)), ('r', np.float64, (5, 1)), ('d', np.int64, (5, 1)),
+                                   ('a_logp', np.float64, (5, 1))])
+    buf.pre_buffer = np.zeros(200, dtype=buf.pre_transition)
+    collect_window_episode(env_buffer, "v4", buf, 77, False)
+    np.random.seed(3)
+    buf.pre_her_func(max_steps=50, newgoal_size_in=4)
+    n = buf.pre_counter
+    pb = buf.pre_buffer[np.linspace(0, n - 1, 48).astype(int)].copy()        # 48 records: real and hindsight ones
+    agent.batch_size, agent.K_epochs = 16, 2
+    agent.heatmapfilename = "x"
+    torch.manual_seed(135)
+    st0 = torch.get_rng_state()
+    agent.update(pb, dev, 0)
+    out["action_loss"] = np.array([v for _, v in agent.writer.scalars["loss/action_loss_update"]])
+    out["value_loss"] = np.array([v for _, v in agent.writer.scalars["loss/value_loss_update"]])
+    torch.set_rng_state(st0)
+    out["perms"] = np.stack([torch.randperm(48).numpy() for _ in range(2)])
+    for tag, net in (("actor", agent.actor), ("critic", agent.critic)):
+        out["upd_%s_sum" % tag] = np.array([x[2] for x in param_stats(net)])
+    for k in buf.pre_transition.names:
+        out["buf_" + k] = pb[k].astype(np.float32) if k == "s" else pb[k]
+    path_out = os.path.join(GOLD, "predictor_update.npz")
+    np.savez_compressed(path_out, **out)
+    print("predictor_update: %d of %d records (%d relabelled done flags), losses" % (48, n, int(pb['d'][:, 0].sum())),
+          out["action_loss"][:2], out["value_loss"][:2], "-> %s (%.1f KB)" % (path_out, os.path.getsize(path_out) / 1024))
+
+
 # ----------------------------------------------------------------------------- self-orientation agent (SURVEY 8 f3)
 def gen_soa():
     """soa/agent/Self_orientation_agent.py: init statistics of the three trainable nets, forward of the orientation
@@ -884,7 +936,7 @@ def gen_mgstep():
     print("mgstep: %d cases -> %s (%.1f KB)" % (ncase, path_out, os.path.getsize(path_out) / 1024))
 
 
-STAGES = {"traces": gen_traces, "views": gen_views, "ppo": gen_ppo, "her": gen_her, "window_her": gen_window_her, "predictor": gen_predictor, "occlusion": gen_occlusion, "mgstep": gen_mgstep, "soa": gen_soa, "pretrain": gen_pretrain}
+STAGES = {"traces": gen_traces, "views": gen_views, "ppo": gen_ppo, "her": gen_her, "window_her": gen_window_her, "predictor": gen_predictor, "predictor_update": gen_predictor_update, "occlusion": gen_occlusion, "mgstep": gen_mgstep, "soa": gen_soa, "pretrain": gen_pretrain}
 
 
 def main(argv):

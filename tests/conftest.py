@@ -18,3 +18,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _default_backend_flags():
+    """Every test starts from PyTorch's default convolution flags: with cudnn.deterministic left on by an earlier test
+    MIOpen picks other solvers (on one box the 7th logged loss of PPO.update then moved by 2.6e-5 for the literal AND
+    the fused path alike, against 1e-6 with the defaults) -- results must not depend on the order of the tests."""
+    import torch
+    torch.backends.cudnn.deterministic = False
+    torch.backends.cudnn.benchmark = False
+    yield

@@ -105,14 +105,14 @@ def test_offline_losses_and_gradients_on_gpu_equal_cpu_at_identical_weights(stag
     assert max(rel) <= 1e-2, rel
 
 
-def test_offline_world_model_training_matches_reference_on_gpu():
+def test_offline_world_model_training_matches_reference_on_gpu(monkeypatch):
     """Whole two-stage training on the device vs the losses the reference logged (CPU run).  Adam(eps = 1e-9) turns
     every near-zero gradient element into a full +-lr step, so reduction-order differences between MIOpen and the
     CPU kernels compound from step to step: the first two steps of each stage (nothing compounded yet) must agree
     within 1e-5 (stage 2: 1e-4, it starts from stage 1's already drifted encoder), the 12-step trajectories within 5e-4
     for the auto-encoder (observed 1.4e-4) and 5e-3 for the 25 M-parameter LSTM (observed 2.6e-3); the per-step
     1e-5 claim is carried by test_offline_losses_and_gradients_on_gpu_equal_cpu_at_identical_weights."""
-    torch.backends.cudnn.deterministic = True
+    monkeypatch.setattr(torch.backends.cudnn, "deterministic", True)      # scoped: restored after this test
     check_offline_world_model_training(DEV, 5e-4, atol_first=1e-5, atol_pre=5e-3)
 
 
@@ -151,3 +151,44 @@ def test_fused_encoder_path_equals_the_module_path():
         ref = agent.decoder(z_pred[:, 3:7])[0]
     assert z_up is not None and fast.shape == ref.shape == (70, 4, 289)
     assert torch.allclose(fast, ref, atol=2e-5, rtol=2e-5)
+
+
+def test_predictor_update_on_window_records_matches_reference():
+    """ppo_predictor.update (PPO_Predictor.py:123-193) on 9-frame window records -- a real episode stored and relabelled by
+    the reference's own pre_store / pre_her_func, 48 records, minibatch 16, 2 epochs -- vs the per-minibatch losses the
+    reference logged (tests/golden/predictor_update.npz), minibatch order replayed.  North-star bound: 1e-5 fp32."""
+    g = dict(np.load(GOLDEN + "/predictor_update.npz"))
+    agent, _, _, _ = check_pred_states_and_heads(DEV, 2.0)           # the seeded weights of the golden run
+    from twoarmy_amd.soa.env_buffer import Buffer_gridworld
+    dt = Buffer_gridworld.window_dtype(17)
+    buf = np.zeros(g["buf_s"].shape[0], dtype=dt)
+    for k in dt.names:
+        buf[k] = g["buf_" + k]
+    agent.batch_size, agent.K_epochs = 16, 2
+    agent.update(buf, DEV, 0, permutations=g["perms"])
+    la = np.array([v for _, v in agent.writer.scalars["loss/action_loss_update"]])
+    lv = np.array([v for _, v in agent.writer.scalars["loss/value_loss_update"]])
+    assert la.shape == g["action_loss"].shape == (6,)
+    np.testing.assert_allclose(la, g["action_loss"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(lv, g["value_loss"], rtol=0, atol=1e-5)
+
+
+def test_predictor_select_action_reference_signature(tmp_path):
+    """select_action(5-deep numpy stacks) acts on frames 1..4 + their predictions (PPO_Predictor.py:85-111): the returned
+    log-prob is the golden probability of the returned action; save_param writes the reference's checkpoint keys."""
+    g = dict(np.load(GOLDEN + "/predictor.npz"))
+    agent, _, _, _ = check_pred_states_and_heads(DEV, 2.0)
+    seen = set()
+    for i in range(3):
+        sm = np.concatenate([g["in_s"][i][:1], g["in_s"][i]])           # frame 0 of the 5-stack is not looked at
+        st = np.concatenate([g["in_p"][i][:1], g["in_p"][i]])
+        for _ in range(4):
+            a, logp = agent.select_action(sm, st, g["in_g"][i], DEV)
+            assert 0 <= a < 5 and abs(logp - float(np.log(g["probs"][i][a]))) < 2e-5
+            seen.add(a)
+    assert len(seen) > 1
+    agent.filepath, agent.name = str(tmp_path), "ppo_predictor_test"
+    ck = torch.load(agent.save_param(3, 0.5), map_location="cpu", weights_only=True)
+    assert set(ck) == {"model_actor", "model_critic", "model_encoder", "model_decoder", "model_predictor", "optimizer_actor",
+                       "optimizer_critic", "epoch"} and ck["epoch"] == 3
+    assert set(ck["model_predictor"]) == set(agent.predictor.state_dict())

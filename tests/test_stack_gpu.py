@@ -38,6 +38,15 @@ def test_facade_env_replays_reference_traces(idx):
         a, g = et.data_env(env)
         assert np.concatenate([a, g]).tolist() == tr["pos"][k].tolist(), ctx
         assert [o.cur_pos for o in env.obstacles] == [tuple(p) for p in tr["balls"][k]], ctx
+        if k % 16 == 0:       # window / auxiliary views of the same state (env_buffer.py:336-362, 430-437)
+            sm9, st9 = et.predata_reset(env)
+            assert sm9.shape == (9, 289) and np.array_equal(sm9[8], tr["matrix"][k]) and st9[0].tolist() == a.tolist()
+            m, m8 = et.pre_col(env)
+            assert np.array_equal(m, tr["matrix"][k]) and m8.shape == (8, 289)
+            st, st10 = et.free_env(env)
+            bx = int(tr["balls"][k][0][0])
+            span = {6: [8, 9, 8, 10], 7: [8, 6, 8, 10]}.get(bx, [8, 6, 8, 7])
+            assert st.tolist() == a.tolist() + span + g.tolist() and st10.shape == (10, 8)
     assert env.action_space.n == 7 and env.actions.done == 6 and et.env_action(env, 4) == 6
     env.close()
 
