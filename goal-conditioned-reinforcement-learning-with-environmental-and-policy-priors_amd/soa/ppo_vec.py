@@ -275,7 +275,18 @@ class VecPPOTrainer:
             # relabelled records: the reference's one-step target with the relabelled goal and reward (PPO.py:112-114)
             assert self.agent.gae_lambda == 0.0 and not self.agent.use_done_mask, "HER records use the TD(0) targets"
             h = self.her
-            hv, hnv = self._values(h["t"], h["n"], self.sample_goal(h["t"], h["n"], h["goal"], h["done"]))
+            hgoal = self.sample_goal(h["t"], h["n"], h["goal"], h["done"])
+            if self.reuse_next_values:
+                # a relabelled prefix is a run of consecutive steps of one episode under ONE goal that ends with its
+                # done record (ppo_her_relabel's emission order), so V(s'_j) of a record that is not done is V(s) of the
+                # record behind it; only the prefix ends are evaluated on their after-states
+                hv = self._values_one(h["t"], h["n"], hgoal, False)
+                hnv = torch.empty_like(hv)
+                hnv[:-1] = hv[1:]
+                ends = torch.nonzero(h["done"]).view(-1)
+                hnv[ends] = self._values_one(h["t"][ends], h["n"][ends], hgoal[ends], True)
+            else:
+                hv, hnv = self._values(h["t"], h["n"], hgoal)
             H = hv.numel()
             hadv, htarget, _ = ppo_ops.gae(h["reward"].view(1, H), hv.view(1, H), hnv.view(1, H), None,
                                            gamma=self.agent.gamma, lam=0.0, use_done_mask=False)

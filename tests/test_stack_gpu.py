@@ -51,6 +51,39 @@ def test_facade_env_replays_reference_traces(idx):
     env.close()
 
 
+def test_view_size_wrapper_reslices_the_state_after_the_step():
+    """ViewSizeWrapper(env, 7) (wrappers.py:428-460) calls gen_obs_grid(7) + encode AFTER env.step() has returned, i.e. on
+    the state after this step's wall drop / patrol spawn, whereas the observation step() itself returns was taken before
+    them (twoarmy_v6.py:182-198 run after MiniGridEnv.step's gen_obs).  So the wrapper's image == the 7x7 view of the
+    CURRENT state (an env built with agent_view_size=7, whose views are pinned by the reference's goldens in
+    tests/test_engine_gpu.py), and differs from that env's step observation exactly at the drop step."""
+    from twoarmy_amd.gym_minigrid import make
+    from twoarmy_amd.gym_minigrid.wrappers import ViewSizeWrapper
+    acts = [2, 2, 1, 1, 2, 2, 2, 0, 3, 1, 2, 2, 2, 2, 1, 2, 6, 2, 2, 2, 0, 0, 2, 2, 2, 1, 1, 1, 2, 2]
+    base = make("MiniGrid-twoarmy-17x17-v4", seed=SEED, env_id=3, tile_size=17)
+    small = make("MiniGrid-twoarmy-17x17-v4", seed=SEED, env_id=3, tile_size=17, agent_view_size=7)
+    env = ViewSizeWrapper(base, agent_view_size=7)
+    assert env.observation_space["image"].shape == (7, 7, 3) and env.action_space.n == 7 and env.agent_pos == base.agent_pos
+    o, o7 = env.reset(), small.reset()
+    assert o["image"].shape == (7, 7, 3) and np.array_equal(o["image"], o7["image"]) and o["direction"] == 3
+    differs = []
+    for k, a in enumerate(acts):
+        pone_before, patrol_before = small.pone, small.patrol
+        (o, r, te, tr, _), (o7, r7, te7, tr7, _) = env.step(a), small.step(a)
+        assert (r, te, tr) == (r7, te7, tr7) and env.agent_pos == small.agent_pos, k
+        assert np.array_equal(o["image"], small.gen_obs()["image"]), k          # the view of the state after the step
+        assert o["image"][3, 6].tolist() == [1, 0, 0]                           # the agent's own cell encodes as empty
+        if not np.array_equal(o["image"], o7["image"]):
+            differs.append(k)
+            assert (small.pone and not pone_before) or (small.patrol and not patrol_before)   # only a drop / spawn step
+        if te or tr:
+            break
+    assert k >= 10 and len(differs) <= 2
+    with pytest.raises(AssertionError):
+        ViewSizeWrapper(base, agent_view_size=4)
+    base.close(); small.close()
+
+
 def test_vecenv_autoreset_semantics():
     from twoarmy_amd.vecenv import TwoarmyVecEnv
     env = TwoarmyVecEnv("MiniGrid-twoarmy-17x17-v6", num_envs=256, seed=SEED)
