@@ -581,6 +581,110 @@ __global__ void ppo_age_scan_kernel(const uint8_t *__restrict__ terminated, cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// World-model decoder, inference only (Net_Decoder, all_net.py:100-137): latent float[64][4][4] per frame ->
+//   ConvTranspose2d(64->16, k2, s2) + ReLU  -> a1[8][8][16]
+//   ConvTranspose2d(16->16, k5, s4) + ReLU  -> a2[33][33][16]
+//   ConvTranspose2d(16->1,  k4, s2)         -> 68x68,  AvgPool2d(4) -> 17x17
+// The last layer and the pooling are both linear, so together they are ONE 3x3 / stride-2 / pad-1 convolution of a2
+// with pre-summed taps (kfold, see ppo_decoder_frames in twoarmy_ppo.h): the 68x68 image never exists.  One workgroup
+// walks frames with a grid stride; weights stay in LDS, a frame's activations never leave LDS (120 KB per workgroup).
+constexpr int DEC_A2 = 33 * 33 * 16;
+
+__global__ __launch_bounds__(256) void ppo_decoder_frames_kernel(const float *__restrict__ z, int n_frames,
+                                                                 const float *__restrict__ w1, const float *__restrict__ b1,
+                                                                 const float *__restrict__ w2, const float *__restrict__ b2,
+                                                                 const float *__restrict__ kfold, float b3,
+                                                                 float *__restrict__ frames) {
+    __shared__ __attribute__((aligned(16))) float W2s[16 * 25 * 16];      // [ci][tap][co]
+    __shared__ __attribute__((aligned(16))) float W1s[64 * 4 * 16];       // [ci][ky*2+kx][co]
+    __shared__ __attribute__((aligned(16))) float Ks[9 * 16];             // [u*3+v][c]
+    __shared__ __attribute__((aligned(16))) float B1s[16], B2s[16];
+    __shared__ __attribute__((aligned(16))) float zs[64 * 16];            // [ci][iy*4+ix]
+    __shared__ __attribute__((aligned(16))) float a1s[64 * 16];           // [oy*8+ox][c]
+    __shared__ __attribute__((aligned(16))) float a2s[DEC_A2];            // [oy*33+ox][c]
+    const int tid = threadIdx.x;
+    // ConvTranspose2d weights are [C_in][C_out][kH][kW]
+    for (int i = tid; i < 16 * 16 * 25; i += 256) {
+        const int ci = i / 400, r = i - ci * 400, co = r / 25, tap = r - co * 25;
+        W2s[(ci * 25 + tap) * 16 + co] = w2[i];
+    }
+    for (int i = tid; i < 64 * 16 * 4; i += 256) {
+        const int ci = i >> 6, r = i & 63, co = r >> 2, k = r & 3;
+        W1s[(ci * 4 + k) * 16 + co] = w1[i];
+    }
+    if (tid < 144) { const int c = tid / 9, t = tid - c * 9; Ks[t * 16 + c] = kfold[tid]; }     // kfold is [c][u][v]
+    if (tid < 16) { B1s[tid] = b1[tid]; B2s[tid] = b2[tid]; }
+    for (int f = blockIdx.x; f < n_frames; f += gridDim.x) {
+        __syncthreads();                                   // weights loaded / previous frame's stage 3 done with a2s
+        for (int i = tid; i < 1024; i += 256) zs[i] = z[(size_t)f * 1024 + i];
+        __syncthreads();
+        // ---- stage 1: every output pixel has exactly one source pixel (k2, s2)
+        for (int o = tid; o < 1024; o += 256) {
+            const int co = o & 15, pix = o >> 4, oy = pix >> 3, ox = pix & 7;
+            const int src = (oy >> 1) * 4 + (ox >> 1), k = (oy & 1) * 2 + (ox & 1);
+            float acc = B1s[co];
+#pragma unroll 8
+            for (int ci = 0; ci < 64; ++ci) acc = fmaf(zs[ci * 16 + src], W1s[(ci * 4 + k) * 16 + co], acc);
+            a1s[pix * 16 + co] = fmaxf(acc, 0.0f);
+        }
+        __syncthreads();
+        // ---- stage 2: output row oy receives input row oy>>2 through tap row oy&3 and, where oy is a multiple of 4,
+        //      input row (oy>>2)-1 through tap row 4 (k5, s4: neighbouring patches overlap by one line); columns alike
+        for (int item = tid; item < 33 * 33 * 4; item += 256) {
+            const int q = item & 3, pix = item >> 2, oy = pix / 33, ox = pix - oy * 33;
+            float4 acc = *reinterpret_cast<const float4 *>(&B2s[q * 4]);
+            const int iy0 = oy >> 2, ky0 = oy & 3, ix0 = ox >> 2, kx0 = ox & 3;
+#pragma unroll
+            for (int ry = 0; ry < 2; ++ry) {
+                const int iy = ry ? iy0 - 1 : iy0, ky = ry ? 4 : ky0;
+                if (ry ? (ky0 != 0 || iy0 == 0) : (iy0 > 7)) continue;
+#pragma unroll
+                for (int rx = 0; rx < 2; ++rx) {
+                    const int ix = rx ? ix0 - 1 : ix0, kx = rx ? 4 : kx0;
+                    if (rx ? (kx0 != 0 || ix0 == 0) : (ix0 > 7)) continue;
+                    const float *a = &a1s[(iy * 8 + ix) * 16];
+                    const float *w = &W2s[(ky * 5 + kx) * 16 + q * 4];
+#pragma unroll
+                    for (int ci = 0; ci < 16; ++ci) {
+                        const float av = a[ci];
+                        const float4 wv = *reinterpret_cast<const float4 *>(w + ci * 400);
+                        acc.x = fmaf(av, wv.x, acc.x); acc.y = fmaf(av, wv.y, acc.y);
+                        acc.z = fmaf(av, wv.z, acc.z); acc.w = fmaf(av, wv.w, acc.w);
+                    }
+                }
+            }
+            acc.x = fmaxf(acc.x, 0.0f); acc.y = fmaxf(acc.y, 0.0f); acc.z = fmaxf(acc.z, 0.0f); acc.w = fmaxf(acc.w, 0.0f);
+            *reinterpret_cast<float4 *>(&a2s[pix * 16 + q * 4]) = acc;
+        }
+        __syncthreads();
+        // ---- stage 3: last transposed conv + 4x4 average pooling = 3x3 / stride 2 / pad 1 over a2
+        for (int o = tid; o < 289; o += 256) {
+            const int y = o / 17, x = o - y * 17;
+            float acc = b3;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int iy = 2 * y + u - 1;
+                if ((unsigned)iy > 32u) continue;
+#pragma unroll
+                for (int v = 0; v < 3; ++v) {
+                    const int ix = 2 * x + v - 1;
+                    if ((unsigned)ix > 32u) continue;
+                    const float4 *a = reinterpret_cast<const float4 *>(&a2s[(iy * 33 + ix) * 16]);
+                    const float4 *k = reinterpret_cast<const float4 *>(&Ks[(u * 3 + v) * 16]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float4 av = a[c], kv = k[c];
+                        acc = fmaf(av.x, kv.x, acc); acc = fmaf(av.y, kv.y, acc);
+                        acc = fmaf(av.z, kv.z, acc); acc = fmaf(av.w, kv.w, acc);
+                    }
+                }
+            }
+            frames[(size_t)f * 289 + o] = acc;
+        }
+    }
+}
+
 int check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TW_OK : TW_E_HIP;
@@ -782,6 +886,15 @@ int ppo_conv1_up4_bwd(const float *frames, int B, int F, const float *gy, const 
                            reinterpret_cast<float4 *>(gb_partial), B);
     else
         return TW_E_ARG;
+    return check_launch();
+}
+
+int ppo_decoder_frames(const float *z, int n_frames, const float *w1, const float *b1, const float *w2, const float *b2,
+                       const float *kfold, float b3, float *frames, void *stream) {
+    if (!z || !w1 || !b1 || !w2 || !b2 || !kfold || !frames || n_frames <= 0) return TW_E_ARG;
+    const int grid = n_frames < 512 ? n_frames : 512;          // 120 KB of LDS: one workgroup per CU, two rounds of them
+    hipLaunchKernelGGL(ppo_decoder_frames_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, z, n_frames, w1, b1, w2,
+                       b2, kfold, b3, frames);
     return check_launch();
 }
 

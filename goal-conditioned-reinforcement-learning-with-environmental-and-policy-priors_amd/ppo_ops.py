@@ -255,3 +255,29 @@ def conv1_up4_bias_relu(frames, weight, bias, folded=None):
     folded: fold_conv1_weights(weight) computed by the caller (e.g. once per rollout), or None."""
     assert frames.is_cuda and frames.dtype == torch.float32 and weight.shape[2:] == (4, 4) and weight.shape[0] == 64
     return _Conv1Up4.apply(frames, weight, bias, folded)
+
+
+def fold_decoder_tail(w3):
+    """ConvTranspose2d(16 -> 1, k4, s2) followed by AvgPool2d(4) (Net_Decoder, all_net.py:100-137) as ONE 3x3 / stride-2 /
+    pad-1 convolution: pooled cell y averages image rows 4y..4y+3, row 4y+d of the transposed conv reads input row 2y+u
+    through tap row d-2u, so input row 2y-1 contributes tap rows {2,3}, row 2y all four, row 2y+1 rows {0,1}."""
+    m = torch.tensor([[0., 0., 1., 1.], [1., 1., 1., 1.], [1., 1., 0., 0.]], dtype=w3.dtype, device=w3.device)
+    return torch.einsum("ur,crs,vs->cuv", m, w3[:, 0], m).mul_(1.0 / 16.0).contiguous()
+
+
+def decoder_frames(z, w1, b1, w2, b2, w3, b3):
+    """Net_Decoder (inference) in one fused pass per frame: z [n,64,4,4] -> predicted 17x17 frames [n,289]
+    (ppo_decoder_frames, include/twoarmy_ppo.h); weights in ConvTranspose2d layout."""
+    assert z.dim() == 4 and tuple(z.shape[1:]) == (64, 4, 4) and z.dtype == torch.float32
+    z = z.contiguous()
+    n = z.shape[0]
+    out = torch.empty((n, 289), dtype=torch.float32, device=z.device)
+    if n:
+        _lib.check(_lib.lib().ppo_decoder_frames(_p(z), n, _p(w1.detach().contiguous(), torch.float32),
+                                                 _p(b1.detach().contiguous(), torch.float32),
+                                                 _p(w2.detach().contiguous(), torch.float32),
+                                                 _p(b2.detach().contiguous(), torch.float32),
+                                                 _p(fold_decoder_tail(w3.detach())), 0.0, _p(out), _stream(z)),
+                   "ppo_decoder_frames")
+        out += b3.detach().view(1, 1)            # the bias as a device-side add: no host synchronisation in the rollout
+    return out

@@ -60,7 +60,7 @@ class ppo_predictor(PPO):
         for i in range(0, state_matrix.shape[0], self.pred_chunk):
             z_c, _ = self.encoder(state_matrix[i:i + self.pred_chunk].reshape(-1, 1, 289), need_upsampled=False)
             z_pred, _ = self.predictor(z_c.view(-1, 4, 64, 4, 4))
-            out.append(self.decoder(z_pred[:, 3:7])[0])
+            out.append(self.decoder(z_pred[:, 3:7], need_full=False)[0])
         return out[0] if len(out) == 1 else torch.cat(out)
 
     def policy_input(self, frames4):

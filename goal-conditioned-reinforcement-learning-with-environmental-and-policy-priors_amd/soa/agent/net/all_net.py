@@ -372,8 +372,17 @@ class Net_Decoder(nn.Module):
         self.apply(reference_init)
         self.pool = nn.AvgPool2d(4, stride=4)
 
-    def forward(self, z):
+    def forward(self, z, need_full=True):
         B, T, D, W, H = z.shape
+        if not need_full and z.is_cuda and z.dtype == torch.float32 and not torch.is_grad_enabled() and \
+                not torch.is_autocast_enabled():
+            # inference of the frozen world model: the three transposed convs + pooling as one fused pass per frame
+            # (ppo_decoder_frames); callers that need the 68x68 image (the training losses) take the module path
+            from .... import ppo_ops
+            c = self.cnn_base
+            frames = ppo_ops.decoder_frames(z.reshape(-1, D, W, H), c[0].weight, c[0].bias, c[2].weight, c[2].bias,
+                                            c[4].weight, c[4].bias)
+            return frames.view(-1, T, CELLS), None
         full = self.cnn_base(z.contiguous().view(-1, D, W, H))
         frames = self.pool(full).view(-1, 1, CELLS).squeeze(-2).reshape(-1, T, CELLS)
         return frames, full.view(-1, T, 1, 4 * GRID, 4 * GRID)

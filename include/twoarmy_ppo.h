@@ -160,6 +160,16 @@ int ppo_conv1_up4_bwd_groups(int B);
 int ppo_conv1_up4_bwd(const float *frames, int B, int F, const float *gy, const float *y, float *gw_partial,
                       float *gb_partial, void *stream);
 
+/* Decoder of the frozen world model, inference only (Net_Decoder, all_net.py:100-137: three ConvTranspose2d with ReLUs
+ * between them, then AvgPool2d(4)), one fused pass per frame:
+ *   z float[n_frames][64][4][4] -> frames float[n_frames][289]   (the 17x17 predicted state matrix)
+ *   w1 float[64][16][2][2], b1[16]; w2 float[16][16][5][5], b2[16]   (ConvTranspose2d layout [C_in][C_out][kH][kW])
+ *   kfold float[16][3][3], b3: the last layer (16 -> 1, k4, s2) and the pooling are linear, hence one 3x3 / stride-2 /
+ *   pad-1 convolution of the second activation: kfold[c][u][v] = 1/16 * sum of w3[c][0][rows R(u)][columns R(v)],
+ *   R(0) = {2, 3}, R(1) = {0, 1, 2, 3}, R(2) = {0, 1}; b3 = the layer's bias.  The 68x68 image is never formed. */
+int ppo_decoder_frames(const float *z, int n_frames, const float *w1, const float *b1, const float *w2, const float *b2,
+                       const float *kfold, float b3, float *frames, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,3 +66,19 @@ def test_unfold_is_the_transpose_of_fold(F):
                 for tx in (0, 1):
                     gwf[py, px, ty, tx] = torch.einsum("bchw,bohw->co", xp[:, :, ty:ty + ny, tx:tx + nx], gsub)
     assert torch.allclose(ops.unfold_conv1_grad(gwf), gw_ref, atol=1e-8)
+
+
+def test_decoder_tail_fold_equals_transposed_conv_plus_pooling():
+    """ppo_ops.fold_decoder_tail: ConvTranspose2d(16 -> 1, k4, s2) + AvgPool2d(4) of Net_Decoder (all_net.py:100-137) ==
+    one 3x3 / stride-2 / pad-1 convolution with the folded taps (what ppo_decoder_frames evaluates from LDS)."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from twoarmy_amd import ppo_ops
+    torch.manual_seed(3)
+    ct = nn.ConvTranspose2d(16, 1, 4, 2)
+    a2 = torch.rand(5, 16, 33, 33) - 0.3
+    with torch.no_grad():
+        want = F.avg_pool2d(ct(a2), 4, 4)
+        got = F.conv2d(a2, ppo_ops.fold_decoder_tail(ct.weight).unsqueeze(0), ct.bias, stride=2, padding=1)
+    assert want.shape == got.shape == (5, 1, 17, 17)
+    assert float((want - got).abs().max()) < 1e-6

@@ -192,3 +192,27 @@ def test_predictor_select_action_reference_signature(tmp_path):
     assert set(ck) == {"model_actor", "model_critic", "model_encoder", "model_decoder", "model_predictor", "optimizer_actor",
                        "optimizer_critic", "epoch"} and ck["epoch"] == 3
     assert set(ck["model_predictor"]) == set(agent.predictor.state_dict())
+
+
+def test_fused_decoder_path_equals_the_module_path():
+    """Net_Decoder inference through ppo_decoder_frames (three transposed convs + pooling fused per frame, the 68x68
+    image never formed) vs the nn.Sequential + AvgPool2d path, on latents the world model really produces and on random
+    ones (negative pre-activations exercise both ReLUs), incl. a frame count that is not a multiple of the grid."""
+    from twoarmy_amd.soa.agent.net.all_net import Net_Decoder
+    from test_predictor_cpu import det_weights_v2
+    torch.manual_seed(2)
+    dec = Net_Decoder()
+    dec.load_state_dict(det_weights_v2(dec, 14))
+    dec.to(DEV).eval()
+    for n, scale in ((3, 1.0), (700, 3.0), (1031, 0.2)):
+        z = (torch.randn(n, 4, 64, 4, 4, device=DEV) * scale)
+        with torch.no_grad():
+            want, full = dec(z)
+            got, none = dec(z, need_full=False)
+        assert none is None and full is not None and got.shape == want.shape == (n, 4, 289)
+        tol = 1e-5 * max(1.0, float(want.abs().max()))
+        assert float((got - want).abs().max()) < tol, (n, float((got - want).abs().max()), tol)
+    # the agent's inference path uses it
+    agent, x, p, goal = check_pred_states_and_heads(DEV, 2.0)
+    s = x[:, :4].contiguous()
+    assert float((agent.pred_frames(s) - agent.pred_states(s)[0]).abs().max()) < 1e-5
