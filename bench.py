@@ -259,7 +259,7 @@ def run_engine_mode(args, rank, world, dev, coll):
     # the engine's own Philox stream, HBM-resident; launches cycle over a fixed window of it
     n_act = min(W + K, 64) if rollout else W + K
     actions = eng.fill_actions(n_act * T).view(n_act, T, N)
-    placement_ms, slab_check_ms = None, None
+    placement_ms, slab_check_ms, slabs = None, None, None
     if rollout and args.placement_candidates > 1:
         out, placement_ms = eng.alloc_outputs_tuned(T, candidates=args.placement_candidates, matrix_codes=args.matrix_codes)
     elif args.torch_outputs or not rollout:
@@ -274,8 +274,9 @@ def run_engine_mode(args, rank, world, dev, coll):
             for s_ in slabs:
                 eng.time_rollout(T, s_, actions=actions[0], iters=2)
             slab_check_ms = [eng.time_rollout(T, s_, actions=actions[0], iters=4) for s_ in slabs]
-            del slabs
             eng.set_state(*state)
+            # the extra slabs stay allocated until the timed region is over: returning gigabytes of physical memory to
+            # the driver right before it was followed (once) by a timed region 21 % slower than the same slab's check
 
     def run(i_begin, n):
         for i in range(i_begin, i_begin + n):
@@ -295,6 +296,7 @@ def run_engine_mode(args, rank, world, dev, coll):
     dt = time.perf_counter() - t0
     ev_ms = e0.elapsed_time(e1)
     dt = max_over_ranks(dt, dev, world)
+    del slabs
 
     bpe = algorithmic_bytes_per_env_step(V, T, 289 if args.matrix_codes else 289 * 4)
     k_ms = ev_ms / K                                    # device time per launch, same K launches as `value`
