@@ -685,6 +685,26 @@ __global__ __launch_bounds__(256) void ppo_decoder_frames_kernel(const float *__
     }
 }
 
+// LSTM cell, pointwise part (torch gate order i, f, g, o): c' = sigmoid(f) c + sigmoid(i) tanh(g), h' = sigmoid(o) tanh(c').
+// gates float[B][4H] already holds x W_ih^T + h W_hh^T + b (two GEMMs); one pass instead of eight elementwise launches.
+__global__ __launch_bounds__(256) void ppo_lstm_cell_kernel(const float4 *__restrict__ gates, float4 *__restrict__ c,
+                                                            float4 *__restrict__ h, int B, int H4) {
+    const int i = blockIdx.x * 256 + threadIdx.x;                 // one float4 of one row's hidden vector
+    if (i >= B * H4) return;
+    const int b = i / H4, j = i - b * H4;
+    const float4 *g = gates + (size_t)b * 4 * H4;
+    const float4 gi = g[j], gf = g[H4 + j], gg = g[2 * H4 + j], go = g[3 * H4 + j];
+    float4 cv = c[i], hv;
+    auto sig = [](float x) { return 1.0f / (1.0f + __expf(-x)); };
+#define LSTM_LANE(m)                                                                                                      \
+    cv.m = sig(gf.m) * cv.m + sig(gi.m) * tanhf(gg.m);                                                                   \
+    hv.m = sig(go.m) * tanhf(cv.m);
+    LSTM_LANE(x) LSTM_LANE(y) LSTM_LANE(z) LSTM_LANE(w)
+#undef LSTM_LANE
+    c[i] = cv;
+    h[i] = hv;
+}
+
 int check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TW_OK : TW_E_HIP;
@@ -895,6 +915,17 @@ int ppo_decoder_frames(const float *z, int n_frames, const float *w1, const floa
     const int grid = n_frames < 512 ? n_frames : 512;          // 120 KB of LDS: one workgroup per CU, two rounds of them
     hipLaunchKernelGGL(ppo_decoder_frames_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, z, n_frames, w1, b1, w2,
                        b2, kfold, b3, frames);
+    return check_launch();
+}
+
+int ppo_lstm_cell(const float *gates, float *c, float *h, int B, int H, void *stream) {
+    if (!gates || !c || !h || B <= 0 || H <= 0 || (H & 3) || (((uintptr_t)gates | (uintptr_t)c | (uintptr_t)h) & 15u))
+        return TW_E_ARG;
+    const long long n = (long long)B * (H / 4);
+    if (n > 0x7fffffffLL) return TW_E_ARG;
+    hipLaunchKernelGGL(ppo_lstm_cell_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4 *>(gates), reinterpret_cast<float4 *>(c), reinterpret_cast<float4 *>(h),
+                       B, H / 4);
     return check_launch();
 }
 

@@ -281,3 +281,14 @@ def decoder_frames(z, w1, b1, w2, b2, w3, b3):
                    "ppo_decoder_frames")
         out += b3.detach().view(1, 1)            # the bias as a device-side add: no host synchronisation in the rollout
     return out
+
+
+def lstm_cell_(gates, c):
+    """LSTM cell pointwise ops in one pass (ppo_lstm_cell): gates [B,4H] (i, f, g, o pre-activations), c [B,H] updated
+    IN PLACE; returns the new hidden state h [B,H]."""
+    B, H4 = gates.shape
+    H = H4 // 4
+    assert c.shape == (B, H) and gates.dtype == c.dtype == torch.float32
+    h = torch.empty_like(c)
+    _lib.check(_lib.lib().ppo_lstm_cell(_p(gates), _p(c), _p(h), B, H, _stream(gates)), "ppo_lstm_cell")
+    return h

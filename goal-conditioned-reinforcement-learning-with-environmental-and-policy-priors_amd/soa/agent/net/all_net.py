@@ -332,10 +332,10 @@ class LSTM(nn.Module):
         Whh = [getattr(m, "weight_hh_l%d" % k) for k in range(L)]
         bias = [getattr(m, "bias_ih_l%d" % k) + getattr(m, "bias_hh_l%d" % k) for k in range(L)]
 
-        def cell(gates, c):
-            i, f, g, o = gates.chunk(4, dim=1)
-            c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
-            return torch.sigmoid(o) * torch.tanh(c), c
+        from .... import ppo_ops
+
+        def cell(gates, c):                                         # pointwise part in one kernel, c updated in place
+            return ppo_ops.lstm_cell_(gates, c), c
 
         h = [z_in.new_zeros(B, 1024) for _ in range(L)]
         c = [z_in.new_zeros(B, 1024) for _ in range(L)]

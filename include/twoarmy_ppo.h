@@ -170,6 +170,11 @@ int ppo_conv1_up4_bwd(const float *frames, int B, int F, const float *gy, const 
 int ppo_decoder_frames(const float *z, int n_frames, const float *w1, const float *b1, const float *w2, const float *b2,
                        const float *kfold, float b3, float *frames, void *stream);
 
+/* Pointwise part of an LSTM cell (nn.LSTM gate order i, f, g, o; the world model's LSTM, all_net.py:52-98, inference):
+ *   gates float[B][4H] = x W_ih^T + h W_hh^T + b_ih + b_hh;   c float[B][H] updated in place;   h float[B][H] written
+ *   c' = sigmoid(f) c + sigmoid(i) tanh(g),   h' = sigmoid(o) tanh(c').   H % 4 == 0, 16-byte aligned pointers. */
+int ppo_lstm_cell(const float *gates, float *c, float *h, int B, int H, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

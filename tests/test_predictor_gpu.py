@@ -131,6 +131,24 @@ def test_lstm_gemm_inference_path_equals_the_miopen_rnn():
     assert torch.allclose(fast, ref.detach(), atol=1e-5, rtol=1e-5)
 
 
+def test_lstm_cell_kernel_vs_torch():
+    """ppo_lstm_cell (gate order i, f, g, o; c updated in place) == the torch expression of nn.LSTM's cell, incl. large
+    pre-activations (saturated gates) and a batch that does not fill the last workgroup."""
+    from twoarmy_amd import ppo_ops
+    torch.manual_seed(8)
+    for B, H, scale in ((3, 1024, 1.0), (2048, 1024, 4.0), (77, 64, 30.0)):
+        gates = torch.randn(B, 4 * H, device=DEV) * scale
+        c0 = torch.randn(B, H, device=DEV)
+        i, f, g, o = gates.double().chunk(4, dim=1)
+        c_want = torch.sigmoid(f) * c0.double() + torch.sigmoid(i) * torch.tanh(g)
+        h_want = torch.sigmoid(o) * torch.tanh(c_want)
+        c = c0.clone()
+        h = ppo_ops.lstm_cell_(gates, c)
+        assert float((c.double() - c_want).abs().max()) < 2e-6 * max(1.0, float(c_want.abs().max()))
+        assert float((h.double() - h_want).abs().max()) < 2e-6
+        assert torch.isfinite(h).all() and torch.isfinite(c).all()
+
+
 def test_fused_encoder_path_equals_the_module_path():
     """ppo_predictor.pred_frames (encoder's first conv fused with the x4 upsampling, eval-mode BatchNorm folded into its
     weights; LSTM as GEMMs) == pred_states[0] through the literal modules, with BatchNorm statistics that are not the
