@@ -7,13 +7,14 @@
 // dir+1 rotate_left calls of the reference are a closed-form index map) into LDS.  process_vis is a row-sequential
 // flood; within a row both of its sweeps are carry chains, so a row of ALL E envs is resolved with 64-bit mask
 // arithmetic on the scalar unit: the "see behind" bits come from one ballot (env e owns bits e*V .. e*V+V-1), the
-// left-to-right sweep is r[i] = m[i] | (r[i-1] & p[i-1]) (Kogge-Stone over the mask, cut at env boundaries), the
+// left-to-right sweep is r[i] = m[i] | (r[i-1] & p[i-1]) (one 64-bit add: the carry IS the flood; cut at env boundaries), the
 // right-to-left sweep its mirror image, and the seeds of the next row are shifts of (reached & see-behind).
 // The encoded images are staged in LDS in output order and leave as aligned dwords.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "minigrid_view.h"
 #include "twoarmy.h"
@@ -36,19 +37,20 @@ __device__ __forceinline__ bool see_behind(uint32_t cell) {     // Wall: never; 
 }
 
 // r[i] = m[i] | (r[i-1] & q[i]): bits of m flood to the right through set bits of q (q[i] = "cell i-1 lets light
-// through and cell i belongs to the same env"); Kogge-Stone over a 64-bit mask on the scalar unit.
+// through and cell i belongs to the same env").  One 64-bit ADD does the whole flood: with R = q | m, the carry that
+// m injects at a seed ripples up through the consecutive ones of R above it and stops at the first zero, so the bits
+// that differ between R + m and R are exactly the flooded run (plus the terminating zero, masked off by R).  A second
+// seed inside a run keeps its bit in the sum (1 + 1 + carry) and passes the carry on: `| m` puts it back.  A carry that
+// crosses into the next env's segment can only pass a bit that is itself a seed there, and whatever lies above a seed
+// is flooded by that seed anyway.  5 scalar instructions instead of a 5-step Kogge-Stone (25).
 __device__ __forceinline__ uint64_t flood_right(uint64_t m, uint64_t q) {
-    uint64_t g = m;
-#pragma unroll
-    for (int d = 1; d < 32; d <<= 1) { g |= (g << d) & q; q &= q << d; }
-    return g;
+    const uint64_t R = q | m;
+    return (((R + m) ^ R) & R) | m;
 }
 
+// r[i] = m[i] | (r[i+1] & q[i]): the mirror image, through a bit reversal (s_brev_b64)
 __device__ __forceinline__ uint64_t flood_left(uint64_t m, uint64_t q) {
-    uint64_t g = m;
-#pragma unroll
-    for (int d = 1; d < 32; d <<= 1) { g |= (g >> d) & q; q &= q >> d; }
-    return g;
+    return __builtin_bitreverse64(flood_right(__builtin_bitreverse64(m), __builtin_bitreverse64(q)));
 }
 
 // One wavefront serves E = 64 / V envs: a view row of all of them sits in one 64-bit mask (env e owns bits
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(64) void mg_gen_obs_kernel(const uint8_t *__restric
 // byte was a third round trip): V = 7 66 -> 56 us on 262 144 random 17x17 worlds.  Measured and rejected: G > 1 env
 // groups per wave (G = 2 / 4: 10-60 % slower at every view size, registers cost occupancy) and staging each
 // (env, plane) span through LDS with 16-byte loads (89 vs 66 us).
-template <int V, int G>
+template <int V, int G, bool ROWS>
 __global__ __launch_bounds__(64) void mg_gen_obs_cols_kernel(const uint8_t *__restrict__ type, const uint8_t *__restrict__ colour,
                                                              const uint8_t *__restrict__ state, int N, int W, int H,
                                                              const int32_t *__restrict__ agent_x,
@@ -206,8 +208,63 @@ __global__ __launch_bounds__(64) void mg_gen_obs_cols_kernel(const uint8_t *__re
     // from overlapping), out-of-world cells at a clamped, always valid address.
     uint8_t tb[G][V], cb[G][V], sb[G][V];
     bool inw[G][V];
+    if constexpr (ROWS) {
+        // Row-wise loads: lane (env, r) fetches window row r of its env -- V consecutive bytes per plane -- as ALIGNED
+        // dwords, re-aligned in registers (v_alignbyte), so every cache line a row touches is requested by ONE
+        // instruction; the byte-per-instruction column walk below asks the L1 for the same lines up to V times, and
+        // with ~130 KB of lines in flight per CU they do not survive in the 32 KB L1 between two requests.  Lanes then
+        // swap (row, column) roles through a V x V dword tile per env in LDS (odd pitch: conflict-free).
+        static_assert(G == 1, "row-wise loads: one env group per wavefront");
+        constexpr int ND = ((V - 1) >> 2) + 2;                             // aligned dwords covering V bytes at any alignment
+        __shared__ uint32_t win[E * VV];
+        const int r = li, lec = le < E ? le : E - 1;
+        const int topx = dir[0] == 0 ? ax[0] : (dir[0] == 2 ? ax[0] - V + 1 : ax[0] - half);
+        const int topy = dir[0] == 1 ? ay[0] : (dir[0] == 3 ? ay[0] - V + 1 : ay[0] - half);
+        const int y = topy + r, yc = min(max(y, 0), H - 1);
+        const bool yin = y >= 0 && y < H;
+        const intptr_t o0 = (intptr_t)n[0] * W * H + (intptr_t)yc * W + topx;      // window-row byte 0, relative to the plane
+        uint32_t rt[ND - 1], rc[ND - 1], rs[ND - 1];
+        auto load_row = [&](const uint8_t *plane, uint32_t *out) {
+            // dwords are clamped to those that contain bytes of the plane array: an in-world cell's dword always is one
+            const intptr_t lo = (intptr_t)((uintptr_t)plane & ~(uintptr_t)3);
+            const intptr_t hi = (intptr_t)(((uintptr_t)plane + (size_t)N * W * H - 1) & ~(uintptr_t)3);
+            const intptr_t P = (intptr_t)(uintptr_t)plane + o0, A = P & ~(intptr_t)3;
+            uint32_t d[ND];
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
+            for (int m = 0; m < ND; ++m) {
+                intptr_t a = A + 4 * m;
+                a = a < lo ? lo : (a > hi ? hi : a);
+                d[m] = *reinterpret_cast<const uint32_t *>(a);
+            }
+            const uint32_t sh = (uint32_t)(P & 3);
+#pragma unroll
+            for (int m = 0; m < ND - 1; ++m) out[m] = __builtin_amdgcn_alignbyte(d[m + 1], d[m], sh);
+        };
+        load_row(type, rt);
+        load_row(colour, rc);
+        if (state) load_row(state, rs);
+        else {
+#pragma unroll
+            for (int m = 0; m < ND - 1; ++m) rs[m] = 0u;
+        }
+#pragma unroll
+        for (int c = 0; c < V; ++c) {
+            const int x = topx + c;
+            const uint32_t t = (rt[c >> 2] >> (8 * (c & 3))) & 255u, co = (rc[c >> 2] >> (8 * (c & 3))) & 255u,
+                           st = (rs[c >> 2] >> (8 * (c & 3))) & 255u;
+            const uint32_t cl = (t <= T_EMPTY) ? EMPTY_CELL : (t | (co << 8) | (st << 16));
+            if (lane < EV) win[(lec * V + r) * V + c] = (yin && x >= 0 && x < W) ? cl : WALL_CELL;   // Grid.slice: outside -> Wall()
+        }
+        wsync();
+        const int k = (dir[0] + 1) & 3;
+        const int sx0 = k == 0 ? i : (k == 1 ? V - 1 : (k == 2 ? V - 1 - i : 0));
+        const int sy0 = k == 0 ? 0 : (k == 1 ? i : (k == 2 ? V - 1 : V - 1 - i));
+        const int dxj = k == 1 ? -1 : (k == 3 ? 1 : 0), dyj = k == 0 ? 1 : (k == 2 ? -1 : 0);
+#pragma unroll
+        for (int j = 0; j < V; ++j) cell[0][j] = win[(lec * V + sy0 + j * dyj) * V + sx0 + j * dxj];
+    }
+#pragma unroll
+    for (int g = 0; g < (ROWS ? 0 : G); ++g) {
         // get_view_exts (minigrid.py:1262-1293) and the number of rotate_left applications
         const int topx = dir[g] == 0 ? ax[g] : (dir[g] == 2 ? ax[g] - V + 1 : ax[g] - half);
         const int topy = dir[g] == 1 ? ay[g] : (dir[g] == 3 ? ay[g] - V + 1 : ay[g] - half);
@@ -232,7 +289,7 @@ __global__ __launch_bounds__(64) void mg_gen_obs_cols_kernel(const uint8_t *__re
 #pragma unroll
     for (int g = 0; g < G; ++g) {
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
+        for (int j = 0; j < (ROWS ? 0 : V); ++j) {
             const uint32_t t = tb[g][j];
             const uint32_t c = (t <= T_EMPTY) ? EMPTY_CELL : (t | ((uint32_t)cb[g][j] << 8) | ((uint32_t)sb[g][j] << 16));
             cell[g][j] = inw[g][j] ? c : WALL_CELL;                       // Grid.slice: outside the world -> Wall()
@@ -374,10 +431,18 @@ extern "C" int mg_gen_obs(const uint8_t *type, const uint8_t *colour, const uint
     do {                                                                                                               \
         constexpr int GG = 1;   /* env groups per wavefront; 2 / 4 measured 10-60 % slower at every view size */        \
         const dim3 grid_g((n_envs + E * GG - 1) / (E * GG));                                                           \
-        hipLaunchKernelGGL((mg_gen_obs_cols_kernel<VT, GG>), grid_g, block, 0, (hipStream_t)stream, type, colour,      \
-                           state, n_envs, width, height, agent_x, agent_y, agent_dir, carrying,                        \
-                           see_through_walls ? 1 : 0, image, image_pitch, vis_mask);                                   \
+        if (rows)                                                                                                      \
+            hipLaunchKernelGGL((mg_gen_obs_cols_kernel<VT, GG, true>), grid_g, block, 0, (hipStream_t)stream, type,    \
+                               colour, state, n_envs, width, height, agent_x, agent_y, agent_dir, carrying,            \
+                               see_through_walls ? 1 : 0, image, image_pitch, vis_mask);                               \
+        else                                                                                                           \
+            hipLaunchKernelGGL((mg_gen_obs_cols_kernel<VT, GG, false>), grid_g, block, 0, (hipStream_t)stream, type,   \
+                               colour, state, n_envs, width, height, agent_x, agent_y, agent_dir, carrying,            \
+                               see_through_walls ? 1 : 0, image, image_pitch, vis_mask);                               \
     } while (0)
+    // row-wise aligned-dword loads (the default); MG_VIEW_LOADS=cols keeps the byte-per-cell column walk (A/B diagnostic)
+    static const bool cols_env = getenv("MG_VIEW_LOADS") && !strcmp(getenv("MG_VIEW_LOADS"), "cols");
+    const bool rows = !cols_env && (size_t)n_envs * width * height >= 64;
     switch (view_size) {                    // the usual odd sizes: lane-per-column kernel with the column in registers
     case 3: MG_LAUNCH_COLS(3); break;
     case 5: MG_LAUNCH_COLS(5); break;
