@@ -169,13 +169,15 @@ __global__ __launch_bounds__(64) void mg_gen_obs_kernel(const uint8_t *__restric
 }
 
 // Compile-time view sizes: lane = (env slot e, view column i) -- the same layout the ballot masks of process_vis use --
-// and the lane keeps its whole column (V cells) in registers: no cell goes through LDS, no per-element div / mod.
-// Counters (rocprofv3 --pmc, V = 7): a wave lives ~35 k cycles for ~860 instructions and waits 73 % of that time
-// (SQ_WAIT_ANY / SQ_WAVE_CYCLES) -- the kernel is bound by dependent memory round trips at full occupancy, so the
-// three plane bytes of every cell are loaded unconditionally and up front (a colour / state load gated on the type
-// byte was a third round trip): V = 7 66 -> 56 us on 262 144 random 17x17 worlds.  Measured and rejected: G > 1 env
-// groups per wave (G = 2 / 4: 10-60 % slower at every view size, registers cost occupancy) and staging each
-// (env, plane) span through LDS with 16-byte loads (89 vs 66 us).
+// and the lane keeps its whole column (V cells) in registers: no per-element div / mod.
+// ROWS (the shipped mode): the plane bytes arrive row-wise as aligned dwords and are transposed through LDS (see the
+// block below); V = 7 occluded 56 -> 41 us, V = 17 see-through 251 -> 143 us on 262 144 random 17x17 worlds.
+// !ROWS (MG_VIEW_LOADS=cols, kept for A/B runs): every lane walks its column with one byte load per cell and plane, all
+// requested up front.  Counters on that variant (rocprofv3 --pmc, V = 7): a wave lives ~35 k cycles for ~860
+// instructions and waits 73 % of that time -- not dependent round trips, as first assumed, but the L1 serving the same
+// lines over and over (V byte loads per line, ~130 KB of lines in flight per CU against 32 KB of L1).
+// Measured and rejected: G > 1 env groups per wave (G = 2 / 4: 10-60 % slower at every view size, registers cost
+// occupancy) and staging each (env, plane) span through LDS with 16-byte loads (89 vs 66 us).
 template <int V, int G, bool ROWS>
 __global__ __launch_bounds__(64) void mg_gen_obs_cols_kernel(const uint8_t *__restrict__ type, const uint8_t *__restrict__ colour,
                                                              const uint8_t *__restrict__ state, int N, int W, int H,
