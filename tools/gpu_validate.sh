@@ -1,13 +1,22 @@
+# Final validation of a build on one MI355X box: smoke, the whole GPU suite, the driver's bench line, the PPO loop,
+# the two-rank rehearsal of the PPO + predictor loop (gloo: one GPU for two ranks), a kernel trace of the headline.
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-timeout -k 10 1100 python -m pytest tests -m gpu -x -q --durations=6 > gpurun_out/r2_suite2.log 2>&1; rc=$?
-tail -14 gpurun_out/r2_suite2.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 || exit 1
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q --durations=5 > gpurun_out/r2_suite_final.log 2>&1; rc=$?
+tail -12 gpurun_out/r2_suite_final.log
 [ $rc -eq 0 ] || exit $rc
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench2 -- python3 bench.py --no-cpu-baseline --steps 40 --warmup 10 > gpurun_out/r2_bench_under_rocprof2.json 2> gpurun_out/r2_prof_bench2.err
-f=$(find gpurun_out/prof_bench2 -name '*kernel_stats.csv' | head -1); head -5 $f | cut -c1-170
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch3 -- python3 bench.py --no-cpu-baseline --steps 8 --warmup 2 > /dev/null 2> gpurun_out/r2_pmc_fetch3.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write3 -- python3 bench.py --no-cpu-baseline --steps 8 --warmup 2 > /dev/null 2> gpurun_out/r2_pmc_write3.err
-python tools/traffic_from_pmc.py gpurun_out/pmc_fetch3 gpurun_out/pmc_write3 > gpurun_out/r2_traffic3.json; grep "traffic_over\|launches" -A1 gpurun_out/r2_traffic3.json | head
-find gpurun_out -name '*counter_collection.csv' -size +20M -delete; find gpurun_out -name '*kernel_trace.csv' -size +20M -delete
-python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r2_bench_final.json 2> gpurun_out/r2_bench_final.err; cat gpurun_out/r2_bench_final.json | cut -c1-400
+python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r2_bench_final.json 2> gpurun_out/r2_bench_final.err || exit 1
+cut -c1-330 gpurun_out/r2_bench_final.json
+timeout -k 10 400 python bench.py --mode ppo --steps 2 --warmup 1 > gpurun_out/r2_bench_ppo_final.json 2> gpurun_out/r2_bench_ppo_final.err || exit 1
+timeout -k 10 400 python bench.py --gpus 2 --mode ppo --predictor --matrix-codes --envs 1024 --minibatch 8192 --steps 1 --warmup 1 > gpurun_out/r2_bench_ppo_predictor_n2_gloo.json 2> gpurun_out/r2_bench_ppo_predictor_n2_gloo.err || exit 1
+python - <<'PY'
+import json
+for f in ("r2_bench_ppo_final", "r2_bench_ppo_predictor_n2_gloo"):
+    d = json.loads(open("gpurun_out/%s.json" % f).read().strip().splitlines()[-1]); c = d["config"]
+    print(f, d["n_gpus"], round(d["value"]), {k: c.get(k) for k in ("rollout_s", "update_s", "update_targets_s", "update_epoch_s")},
+          c.get("collective"), {k: v for k, v in c.get("grad_bucket", {}).items() if k.startswith("ms") or k == "allreduces_timed"})
+PY
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_final -- python3 bench.py --no-cpu-baseline --steps 40 --warmup 10 > gpurun_out/r2_bench_under_rocprof_final.json 2> gpurun_out/r2_prof_final.err
+f=$(find gpurun_out/prof_final -name '*kernel_stats.csv' | head -1); head -4 $f | cut -c1-170
+find gpurun_out -name '*kernel_trace.csv' -size +20M -delete
