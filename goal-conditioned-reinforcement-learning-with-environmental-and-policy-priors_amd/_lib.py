@@ -92,7 +92,7 @@ _SIGS.update({
                                   _vp, _vp, _vp, _vp, _vp]),
     "ppo_her_relabel_window": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u64, C.c_uint32, C.c_uint32, _i, _i, _i, _i, _vp,
                                          _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "ppo_lstm_cell": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp]),
+    "ppo_lstm_cell": (C.c_int, [_vp, _vp, C.c_longlong, _vp, _vp, _vp, _i, _i, _vp]),
     "ppo_decoder_frames": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp]),
     "ppo_gather_stack_u8": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "ppo_age_scan": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp, _vp]),

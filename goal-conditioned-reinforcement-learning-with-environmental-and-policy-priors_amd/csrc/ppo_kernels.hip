@@ -686,14 +686,27 @@ __global__ __launch_bounds__(256) void ppo_decoder_frames_kernel(const float *__
 }
 
 // LSTM cell, pointwise part (torch gate order i, f, g, o): c' = sigmoid(f) c + sigmoid(i) tanh(g), h' = sigmoid(o) tanh(c').
-// gates float[B][4H] already holds x W_ih^T + h W_hh^T + b (two GEMMs); one pass instead of eight elementwise launches.
-__global__ __launch_bounds__(256) void ppo_lstm_cell_kernel(const float4 *__restrict__ gates, float4 *__restrict__ c,
-                                                            float4 *__restrict__ h, int B, int H4) {
+// The pre-activations are the sum of up to three terms, added here instead of in GEMM epilogues / copy kernels:
+// gates_a float[B][4H] (a GEMM result), gates_b (optional, rows ldb floats apart: the slice of one time step out of
+// the input projections of all known steps) and bias (optional, float[4H]).  One pass instead of eight elementwise
+// launches plus the strided copy torch.addmm makes of a non-contiguous addend.
+__global__ __launch_bounds__(256) void ppo_lstm_cell_kernel(const float4 *__restrict__ ga, const float4 *__restrict__ gb,
+                                                            long long ldb4, const float4 *__restrict__ bias,
+                                                            float4 *__restrict__ c, float4 *__restrict__ h, int B, int H4) {
     const int i = blockIdx.x * 256 + threadIdx.x;                 // one float4 of one row's hidden vector
     if (i >= B * H4) return;
     const int b = i / H4, j = i - b * H4;
-    const float4 *g = gates + (size_t)b * 4 * H4;
-    const float4 gi = g[j], gf = g[H4 + j], gg = g[2 * H4 + j], go = g[3 * H4 + j];
+    float4 gi = make_float4(0.f, 0.f, 0.f, 0.f), gf = gi, gg = gi, go = gi;
+    if (ga) {
+        const float4 *g = ga + (size_t)b * 4 * H4;
+        gi = g[j]; gf = g[H4 + j]; gg = g[2 * H4 + j]; go = g[3 * H4 + j];
+    }
+    auto add4 = [](float4 &a, const float4 &v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; };
+    if (gb) {
+        const float4 *q = gb + (size_t)b * ldb4;
+        add4(gi, q[j]); add4(gf, q[H4 + j]); add4(gg, q[2 * H4 + j]); add4(go, q[3 * H4 + j]);
+    }
+    if (bias) { add4(gi, bias[j]); add4(gf, bias[H4 + j]); add4(gg, bias[2 * H4 + j]); add4(go, bias[3 * H4 + j]); }
     float4 cv = c[i], hv;
     auto sig = [](float x) { return 1.0f / (1.0f + __expf(-x)); };
 #define LSTM_LANE(m)                                                                                                      \
@@ -918,13 +931,18 @@ int ppo_decoder_frames(const float *z, int n_frames, const float *w1, const floa
     return check_launch();
 }
 
-int ppo_lstm_cell(const float *gates, float *c, float *h, int B, int H, void *stream) {
-    if (!gates || !c || !h || B <= 0 || H <= 0 || (H & 3) || (((uintptr_t)gates | (uintptr_t)c | (uintptr_t)h) & 15u))
+int ppo_lstm_cell(const float *gates_a, const float *gates_b, long long ldb, const float *bias, float *c, float *h, int B,
+                  int H, void *stream) {
+    if ((!gates_a && !gates_b) || !c || !h || B <= 0 || H <= 0 || (H & 3) ||
+        (((uintptr_t)gates_a | (uintptr_t)c | (uintptr_t)h) & 15u))
         return TW_E_ARG;
+    if (gates_b && ((((uintptr_t)gates_b) & 15u) || (ldb & 3) || ldb < 4LL * H)) return TW_E_ARG;
+    if (bias && (((uintptr_t)bias) & 15u)) return TW_E_ARG;
     const long long n = (long long)B * (H / 4);
     if (n > 0x7fffffffLL) return TW_E_ARG;
     hipLaunchKernelGGL(ppo_lstm_cell_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const float4 *>(gates), reinterpret_cast<float4 *>(c), reinterpret_cast<float4 *>(h),
+                       reinterpret_cast<const float4 *>(gates_a), reinterpret_cast<const float4 *>(gates_b), ldb / 4,
+                       reinterpret_cast<const float4 *>(bias), reinterpret_cast<float4 *>(c), reinterpret_cast<float4 *>(h),
                        B, H / 4);
     return check_launch();
 }

@@ -283,12 +283,18 @@ def decoder_frames(z, w1, b1, w2, b2, w3, b3):
     return out
 
 
-def lstm_cell_(gates, c):
-    """LSTM cell pointwise ops in one pass (ppo_lstm_cell): gates [B,4H] (i, f, g, o pre-activations), c [B,H] updated
-    IN PLACE; returns the new hidden state h [B,H]."""
-    B, H4 = gates.shape
-    H = H4 // 4
-    assert c.shape == (B, H) and gates.dtype == c.dtype == torch.float32
+def lstm_cell_(gates, c, gates_b=None, bias=None):
+    """LSTM cell pointwise ops in one pass (ppo_lstm_cell): pre-activations gates [B,4H] (i, f, g, o; None: zero) + gates_b (optional
+    [B,4H] view whose rows may be strided, e.g. xin[:, t] of a [B,T,4H] tensor) + bias (optional [4H]); c [B,H] is
+    updated IN PLACE; returns the new hidden state h [B,H]."""
+    B, H = c.shape
+    H4 = 4 * H
+    assert c.dtype == torch.float32 and (gates is not None or gates_b is not None)
+    assert gates is None or (gates.shape == (B, H4) and gates.dtype == torch.float32)
+    pb, ldb = None, 0
+    if gates_b is not None:
+        assert gates_b.shape == (B, H4) and gates_b.stride(1) == 1 and gates_b.dtype == torch.float32 and gates_b.is_cuda
+        pb, ldb = C.c_void_p(gates_b.data_ptr()), gates_b.stride(0) if B > 1 else H4
     h = torch.empty_like(c)
-    _lib.check(_lib.lib().ppo_lstm_cell(_p(gates), _p(c), _p(h), B, H, _stream(gates)), "ppo_lstm_cell")
+    _lib.check(_lib.lib().ppo_lstm_cell(_p(gates), pb, ldb, _p(bias), _p(c), _p(h), B, H, _stream(c)), "ppo_lstm_cell")
     return h

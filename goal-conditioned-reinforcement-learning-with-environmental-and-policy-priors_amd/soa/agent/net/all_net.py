@@ -333,18 +333,16 @@ class LSTM(nn.Module):
         bias = [getattr(m, "bias_ih_l%d" % k) + getattr(m, "bias_hh_l%d" % k) for k in range(L)]
 
         from .... import ppo_ops
-
-        def cell(gates, c):                                         # pointwise part in one kernel, c updated in place
-            return ppo_ops.lstm_cell_(gates, c), c
-
-        h = [z_in.new_zeros(B, 1024) for _ in range(L)]
+        bias = [b.contiguous() for b in bias]
+        h = [None] * L                                              # zero initial state: h enters no GEMM at t = 0
         c = [z_in.new_zeros(B, 1024) for _ in range(L)]
         x = z_in                                                    # [B, T, 1024]: the layer's inputs for the known steps
         for k in range(L):
-            xin = torch.addmm(bias[k], x.reshape(B * T, -1), Wih[k].t()).view(B, T, -1)      # one GEMM for all T steps
+            xin = torch.mm(x.reshape(B * T, -1), Wih[k].t()).view(B, T, -1)                  # one GEMM for all T steps
             outs = []
-            for t in range(T):
-                h[k], c[k] = cell(torch.addmm(xin[:, t], h[k], Whh[k].t()), c[k])
+            for t in range(T):                # h W_hh^T as a plain GEMM (none at t = 0: h is zero); + xin[:, t] (strided
+                rec = torch.mm(h[k], Whh[k].t()) if t else None              # view) + bias inside the cell kernel
+                h[k] = ppo_ops.lstm_cell_(rec, c[k], xin[:, t], bias[k])
                 outs.append(h[k])
             x = torch.stack(outs, dim=1)
         seq = [x]
@@ -352,8 +350,9 @@ class LSTM(nn.Module):
         for _ in range(self.nt - 4 - 1):
             inp = z_n
             for k in range(L):
-                gates = torch.addmm(bias[k], inp, Wih[k].t())
-                h[k], c[k] = cell(torch.addmm(gates, h[k], Whh[k].t()), c[k])
+                gates = torch.mm(inp, Wih[k].t())
+                gates.addmm_(h[k], Whh[k].t())                      # in place: no copy of the addend
+                h[k] = ppo_ops.lstm_cell_(gates, c[k], None, bias[k])
                 inp = h[k]
             z_n = inp
             seq.append(z_n.unsqueeze(1))

@@ -171,9 +171,12 @@ int ppo_decoder_frames(const float *z, int n_frames, const float *w1, const floa
                        const float *kfold, float b3, float *frames, void *stream);
 
 /* Pointwise part of an LSTM cell (nn.LSTM gate order i, f, g, o; the world model's LSTM, all_net.py:52-98, inference):
- *   gates float[B][4H] = x W_ih^T + h W_hh^T + b_ih + b_hh;   c float[B][H] updated in place;   h float[B][H] written
+ *   pre-activations = gates_a float[B][4H] (NULL: absent, e.g. the first step, whose hidden state is zero)  (+ gates_b: rows ldb floats apart, e.g. one time step of the input
+ *   projections float[B][T][4H] -> ldb = T * 4H;  NULL: absent)  (+ bias float[4H]; NULL: absent)
+ *   c float[B][H] updated in place;   h float[B][H] written
  *   c' = sigmoid(f) c + sigmoid(i) tanh(g),   h' = sigmoid(o) tanh(c').   H % 4 == 0, 16-byte aligned pointers. */
-int ppo_lstm_cell(const float *gates, float *c, float *h, int B, int H, void *stream);
+int ppo_lstm_cell(const float *gates_a, const float *gates_b, long long ldb, const float *bias, float *c, float *h, int B,
+                  int H, void *stream);
 
 #ifdef __cplusplus
 }

@@ -147,6 +147,19 @@ def test_lstm_cell_kernel_vs_torch():
         assert float((c.double() - c_want).abs().max()) < 2e-6 * max(1.0, float(c_want.abs().max()))
         assert float((h.double() - h_want).abs().max()) < 2e-6
         assert torch.isfinite(h).all() and torch.isfinite(c).all()
+        # the same pre-activations split into GEMM result + strided slice of the input projections + bias, and with
+        # the GEMM result absent (first step)
+        xin = torch.randn(B, 3, 4 * H, device=DEV) * scale
+        bias = torch.randn(4 * H, device=DEV)
+        ga = gates - xin[:, 1] - bias
+        c2 = c0.clone()
+        h2 = ppo_ops.lstm_cell_(ga, c2, xin[:, 1], bias)
+        assert float((h2 - h).abs().max()) < 1e-5 * max(1.0, scale) and float((c2 - c).abs().max()) < 1e-5 * max(1.0, scale)
+        c3 = c0.clone()
+        h3 = ppo_ops.lstm_cell_(None, c3, xin[:, 2], bias)
+        c4 = c0.clone()
+        h4 = ppo_ops.lstm_cell_((xin[:, 2] + bias).contiguous(), c4)
+        assert float((h3 - h4).abs().max()) < 2e-6 and float((c3 - c4).abs().max()) < 2e-6 * max(1.0, float(c4.abs().max()))
 
 
 def test_fused_encoder_path_equals_the_module_path():
