@@ -216,17 +216,21 @@ def test_trainer_with_device_her_records():
     eng.close()
 
 
-def test_hindsight_records_across_the_rollout_boundary():
+@pytest.mark.parametrize("window_records", [False, True])
+def test_hindsight_records_across_the_rollout_boundary(window_records):
     """Episodes that start in one rollout and end in the next: relabel() works on the two-rollout window and returns
-    the records that lie in the current rollout -- equal to the oracle run over the concatenated rollouts."""
+    the records that lie in the current rollout -- equal to the oracle run over the concatenated rollouts.  With the
+    predictor agent the relabelling is the window-record variant (pre_her_func: goal candidates from the fifth step)."""
     import her_oracle
     from twoarmy_amd.engine import TwoarmyEngine
     from twoarmy_amd.soa.agent.PPO import PPO
+    from twoarmy_amd.soa.agent.PPO_Predictor import ppo_predictor
     from twoarmy_amd.soa.ppo_vec import VecPPOTrainer
     torch.manual_seed(4)
     N, T = 48, 40                                   # 50-step episodes: every second episode straddles a boundary
+    skip = 4 if window_records else 0
     eng = TwoarmyEngine(4, N, 17, seed=SEED)
-    tr = VecPPOTrainer(PPO(), eng, rollout_steps=T, minibatch=512)
+    tr = VecPPOTrainer(ppo_predictor() if window_records else PPO(), eng, rollout_steps=T, minibatch=512)
     tr.collect()
     first = {k: v.clone() for k, v in dict(pos=tr.pos[4:], term=tr.term, trunc=tr.trunc, reward=tr.reward, age0=tr.age[0]).items()}
     h1 = tr.relabel()
@@ -237,7 +241,7 @@ def test_hindsight_records_across_the_rollout_boundary():
     cat = lambda a, b: np.concatenate([a.cpu().numpy(), b.cpu().numpy()])          # noqa: E731
     want = her_oracle.relabel(cat(first["pos"], tr.pos[4:]), cat(first["term"], tr.term), cat(first["trunc"], tr.trunc),
                               first["age0"].cpu().numpy(), cat(first["reward"], tr.reward), seed=tr.her_seed,
-                              env_id0=0, step0=0)
+                              env_id0=0, step0=0, skip=skip)
     keep = want["t"] >= T
     assert keep.sum() > 0 and (want["t"][keep] - T < 10).sum() > 0       # records right after the boundary: straddling episodes
     for k in ("n", "goal", "reward", "done"):
@@ -245,7 +249,8 @@ def test_hindsight_records_across_the_rollout_boundary():
     assert np.array_equal(h2["t"].cpu().numpy(), want["t"][keep] - T)
     # the first rollout on its own was relabelled with the same picks (same global step keys)
     w1 = her_oracle.relabel(first["pos"].cpu().numpy(), first["term"].cpu().numpy(), first["trunc"].cpu().numpy(),
-                            first["age0"].cpu().numpy(), first["reward"].cpu().numpy(), seed=tr.her_seed, env_id0=0, step0=0)
+                            first["age0"].cpu().numpy(), first["reward"].cpu().numpy(), seed=tr.her_seed, env_id0=0, step0=0,
+                            skip=skip)
     assert np.array_equal(h1["t"].cpu().numpy(), w1["t"]) and np.array_equal(h1["goal"].cpu().numpy(), w1["goal"])
     eng.close()
 
