@@ -1197,6 +1197,12 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
     uint32_t w1 = d.pone ? 0x30u : 0u, w2 = d.pone ? 3u << d.i2 : 0u;
     uint32_t dynw = d.pone ? (((uint32_t)(d.i1 - 9) & 3u) << 17) | (((uint32_t)(d.i2 - 6) & 3u) << 19) | (1u << 22) : 0u;
     if (d.patrol) dynw |= 1u << 24;
+    // v4 patrol state machines (see the logic loop); a patrol outside its range cannot be encoded: sequential kernel
+    if (V4) {
+        bad |= d.patrol && (((unsigned)(d.o1y0 - 3) > 2u) | ((unsigned)(d.o2x0 - 5) > 5u));
+        if (s.upd_long) s.upd_horiz = 0;              // twoarmy_v4.py:116,148: the first step leaves exactly one of them set
+    }
+    int s1 = (min(max(d.o1y0, 3), 5) - 3) * 2 + (s.up1 != 0), s2 = (min(max(d.o2x0, 5), 10) - 5) * 2 + (s.right2 != 0);
 
     for (int c0 = 0; c0 < p.T; c0 += PCH) {
         const int len = min(PCH, p.T - c0);
@@ -1255,27 +1261,24 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
                     // (7 at reset, +1 for m6 in {0,1}, -1 for {2,3}, 0 for {4,5}); verified against the record at launch
                     const int b0 = (int)((0x666787u >> (4 * m6)) & 15u);
                     if (V4) {                                             // twoarmy_v4.py:115-176
-                        if (s.upd_long) {
-                            s.upd_horiz = 0;
-                            bool go = (s.m4 == 2) | (m6 == 3) | (m6 == 0);
-                            go |= (dr & 1u) != 0u;
-                            if (go && d.patrol) {
-                                d.o1y0 += s.up1 ? -1 : 1;
-                                if (s.up1) { if (d.o1y0 == 3) s.up1 = 0; } else { if (d.o1y0 + 2 == 7) s.up1 = 1; }
-                            }
-                        }
-                        if (s.upd_horiz) {
-                            s.upd_long = 0;
-                            bool go = (m6 != 1);
-                            go |= (dr & 1u) != 0u;
-                            if (go && d.patrol) {
-                                d.o2x0 += s.right2 ? 1 : -1;
-                                if (s.right2) { if (d.o2x0 + 1 == 11) s.right2 = 0; } else { if (d.o2x0 == 5) s.right2 = 1; }
-                            }
-                        }
-                        bad |= d.patrol && (((unsigned)(d.o1y0 - 3) > 2u) | ((unsigned)(d.o2x0 - 5) > 5u));
-                        d.o1y0 = min(max(d.o1y0, 3), 5); d.o2x0 = min(max(d.o2x0, 5), 10);
+                        // column patrol (y, up1) and square patrol (x, right2) as two small state machines:
+                        // s1 = (y - 3) * 2 + up1, s2 = (x - 5) * 2 + right2, one table lookup per move.  The gates are
+                        // bit tables over step_move % 6: the column moves when m6 in {0, 3} (or m4 == 2, or the drawn
+                        // gate), the square when m6 != 1 (or the gate).  States that would leave the range -- (3, up),
+                        // (5, down), (10, right), (5, left); never reached in play -- map to themselves and raise `bad`,
+                        // which is what the literal move + range check + clamp does.
+                        const uint32_t gate = dr & 1u;
+                        const uint32_t gl = (((0x09u >> m6) | gate) & 1u) | (uint32_t)(s.m4 == 2);
+                        const uint32_t gh = ((0x3Du >> m6) | gate) & 1u;
+                        const bool mv1 = (gl & (uint32_t)s.upd_long & (uint32_t)d.patrol) != 0u;
+                        const bool mv2 = (gh & (uint32_t)s.upd_horiz & (uint32_t)d.patrol) != 0u;
+                        bad |= (mv1 & ((s1 == 1) | (s1 == 4))) | (mv2 & ((s2 == 0) | (s2 == 11)));
+                        const int n1 = (int)((0x1C14Au >> (3 * s1)) & 7u);                    // 0>2 1>1 2>5 3>0 4>4 5>3
+                        const int n2 = (int)(((s2 < 8 ? 0x94725130u : 0xB8A6u) >> (4 * (s2 & 7))) & 15u);
+                        s1 = mv1 ? n1 : s1;                               // 0>0 1>3 2>1 3>5 4>2 5>7 6>4 7>9 | 8>6 9>10 10>8 11>11
+                        s2 = mv2 ? n2 : s2;
                     }
+                    const int py1 = 3 + (s1 >> 1), px2 = 5 + (s2 >> 1);   // patrol column top row / square left column
                     // MiniGridEnv.step (minigrid.py:1333-1441): is the target cell free?  One bitmask per grid row
                     // (bit x set = cell (x, ty) blocks): border / row-8 walls + ball triple + dropped 2x2 wall blocks
                     // (+ patrol column and square).  The goal cell (14, 2) is never blocked.
@@ -1288,8 +1291,8 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
                     rb |= (unsigned)(ty - 11) <= 1u ? w2 : 0u;
                     if (V4) {
                         const uint32_t pm = d.patrol ? ~0u : 0u;
-                        rb |= (unsigned)(ty - d.o1y0) <= 2u ? ((1u << 12) & pm) : 0u;
-                        rb |= (unsigned)(ty - 4) <= 1u ? ((3u << d.o2x0) & pm) : 0u;
+                        rb |= (unsigned)(ty - py1) <= 2u ? ((1u << 12) & pm) : 0u;
+                        rb |= (unsigned)(ty - 4) <= 1u ? ((3u << px2) & pm) : 0u;
                     }
                     const bool enter = ((rb >> tx) & 1u) == 0u;
                     s.ax = enter ? tx : s.ax;
@@ -1305,9 +1308,9 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
                         w1 = 0x30u; w2 = 3u << d.i2;
                         dynw = (dynw & ~(15u << 17)) | ((uint32_t)(d.i1 - 9) << 17) | ((uint32_t)(d.i2 - 6) << 19) | (1u << 22);
                     }
-                    if (V4 && !d.patrol && s.ay <= 8) {
-                        d.o2x0 = 6 + (int)((dr >> 5) & 3u);
-                        d.o1y0 = 4;
+                    if (V4 && !d.patrol && s.ay <= 8) {                    // column at rows 4..6, square at x = 6 + draw
+                        s2 = (int)((1u + ((dr >> 5) & 3u)) << 1) | (s2 & 1);
+                        s1 = 2 | (s1 & 1);
                         d.patrol = 1;
                         dynw |= 1u << 24;
                     }
@@ -1317,11 +1320,13 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
                     bool hit = in_span & (s.ay == 8);
                     reward = hit ? R_HIT : reward;
                     reward = (in_span & (s.ay == 9)) ? R_RISK : reward;
-                    if (V4 && d.patrol) {
-                        const bool sq_rows = (unsigned)(s.ay - 4) <= 1u, col_rows = (unsigned)(s.ay - d.o1y0) <= 2u;
-                        const bool prisk = ((s.ay == 6) & ((unsigned)(s.ax - d.o2x0) <= 1u)) | ((s.ax == d.o2x0 - 1) & sq_rows) |
-                                           ((s.ax == d.o2x0 + 2) & sq_rows) | ((s.ax == 11) & col_rows);
-                        const bool phit = ((s.ax == 12) & col_rows) | (((unsigned)(s.ax - d.o2x0) <= 1u) & sq_rows);
+                    if (V4) {                                              // twoarmy_v4.py:242-280, as column bitmasks of row ay
+                        const int y1 = 3 + (s1 >> 1), x2 = 5 + (s2 >> 1);  // after this step's spawn
+                        const uint32_t pm = d.patrol ? ~0u : 0u;
+                        const uint32_t colr = (unsigned)(s.ay - y1) <= 2u ? pm : 0u, sqr = (unsigned)(s.ay - 4) <= 1u ? pm : 0u;
+                        const uint32_t hitm = (colr & (1u << 12)) | (sqr & (3u << x2));
+                        const uint32_t riskm = (colr & (1u << 11)) | (sqr & (9u << (x2 - 1))) | ((s.ay == 6 ? pm : 0u) & (3u << x2));
+                        const bool phit = ((hitm >> s.ax) & 1u) != 0u, prisk = ((riskm >> s.ax) & 1u) != 0u;
                         reward = prisk ? R_RISK : reward;
                         reward = phit ? R_HIT : reward;
                         hit |= phit;
@@ -1338,11 +1343,11 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
                     uint32_t rec = (uint32_t)s.ax | ((uint32_t)s.ay << 5) | ((uint32_t)(b0 - 6) << 10) | dynw | (seen >> 1) |
                                    ((uint32_t)reward << 25) | ((uint32_t)terminated << 28) | ((uint32_t)(truncated != 0) << 29) |
                                    REC_VALID;
-                    if (V4) rec |= ((uint32_t)(d.o1y0 - 3) << 12) | ((uint32_t)(d.o2x0 - 5) << 14);
+                    if (V4) rec |= ((uint32_t)(s1 >> 1) << 12) | ((uint32_t)(s2 >> 1) << 14);
                     if (terminated || truncated) {                        // twoarmy_v6.py:296-318 + auto-reset
                         s.step_move = 0; s.m6 = 0; s.m4 = 0; s.first_room2 = 1; s.risk = 0;
                         const int ca = (dr >> 7) & 1, cb = (dr >> 8) & 1;
-                        s.up1 = 1 - ca; s.right2 = ca;
+                        s1 = 1 - ca; s2 = ca;                             // up1 = 1 - ca, right2 = ca; no patrol until the next spawn
                         s.upd_horiz = 1 - cb; s.upd_long = cb;
                         s.episodes += 1;
                         d.pone = 0; d.patrol = 0; w1 = 0u; w2 = 0u; dynw = 0u;
@@ -1501,6 +1506,7 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
     // ---- write the final state (records from the logic lanes, planes from the closed form)
     if (wave == 0 && lane < PG) {
         int32_t *r = recs + lane * REC;
+        if (V4) { s.up1 = s1 & 1; s.right2 = s2 & 1; d.o1y0 = 3 + (s1 >> 1); d.o2x0 = 5 + (s2 >> 1); }
         r[TW_AX] = s.ax; r[TW_AY] = s.ay; r[TW_STEP_COUNT] = s.step_count; r[TW_STEP_MOVE] = s.step_move;
         r[TW_UP1] = s.up1; r[TW_RIGHT2] = s.right2; r[TW_UPD_LONG] = s.upd_long; r[TW_UPD_HORIZ] = s.upd_horiz;
         r[TW_RISK] = s.risk; r[TW_FIRST_ROOM2] = s.first_room2; r[TW_EPISODES] = s.episodes;
