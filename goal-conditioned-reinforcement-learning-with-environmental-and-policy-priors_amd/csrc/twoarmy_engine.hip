@@ -1506,7 +1506,8 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
     // ---- write the final state (records from the logic lanes, planes from the closed form)
     if (wave == 0 && lane < PG) {
         int32_t *r = recs + lane * REC;
-        if (V4) { s.up1 = s1 & 1; s.right2 = s2 & 1; d.o1y0 = 3 + (s1 >> 1); d.o2x0 = 5 + (s2 >> 1); }
+        s.up1 = s1 & 1; s.right2 = s2 & 1;                   // the episode-end coins live in the low bits of s1 / s2 (v6 too)
+        if (V4) { d.o1y0 = 3 + (s1 >> 1); d.o2x0 = 5 + (s2 >> 1); }
         r[TW_AX] = s.ax; r[TW_AY] = s.ay; r[TW_STEP_COUNT] = s.step_count; r[TW_STEP_MOVE] = s.step_move;
         r[TW_UP1] = s.up1; r[TW_RIGHT2] = s.right2; r[TW_UPD_LONG] = s.upd_long; r[TW_UPD_HORIZ] = s.upd_horiz;
         r[TW_RISK] = s.risk; r[TW_FIRST_ROOM2] = s.first_room2; r[TW_EPISODES] = s.episodes;
