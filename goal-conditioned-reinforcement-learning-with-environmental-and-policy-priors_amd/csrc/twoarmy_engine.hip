@@ -1211,7 +1211,7 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
         for (int i = tid; i < len * PG; i += 64 * PWAVES) {
             const int tl = i / PG, e = i - tl * PG;
             const int act_in = (n0 + e < N) ? p.actions[(size_t)(c0 + tl) * N + n0 + e] : 0;
-            ring[i] = 0u;
+            ring[i] = (n0 + e < N) ? 0u : REC_VALID;        // padding envs of a ragged last block are "done" from the start
             // The draw counter of an env advances by one per step whatever happens, so every Philox word of
             // the chunk is known up front: all 16 waves compute them in parallel and the serial logic wave
             // only reads one packed word per step (bit0 gate==6, 1-2 wall1, 3-4 wall2, 5-6 spawn, 7 coin A, 8 coin B).
@@ -1248,8 +1248,9 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
             PSTAMP(pst_t0);
             __builtin_amdgcn_s_setprio(3);        // the serial chain must win issue arbitration on its SIMD
             uint32_t dr_next = drw[lane < PG ? lane : 0], badw = 0u, last_rec = 0u;
-            for (int tl = 0; tl < len; ++tl) {
-                if (lg_active) {
+            // the whole loop sits inside the lane predicate: one exec set-up per chunk instead of an if / else per step
+            if (lg_active) for (int tl = 0; tl < len; ++tl) {
+                {
                     const uint32_t dr = dr_next;
                     dr_next = drw[min(tl + 1, len - 1) * PG + lane];      // next step's word: its LDS latency leaves the chain
                     badw |= dr;                                           // bit 20: the reference raises on this action
@@ -1356,7 +1357,6 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
                     last_rec = rec;
                     ring[tl * PG + lane] = rec;
                 }
-                else if (lane < PG) ring[tl * PG + lane] = REC_VALID;   // padding env of a ragged last block
             }
             if (lg_active) {                                              // what the loop left for the end of the chunk
                 s.t += (uint32_t)len;                                     // one draw-counter tick per step, whatever happens
