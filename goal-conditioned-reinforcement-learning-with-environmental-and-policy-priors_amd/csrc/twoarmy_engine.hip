@@ -1247,12 +1247,16 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
             // ================= LOGIC: the transition in closed form, one step per iteration
             PSTAMP(pst_t0);
             __builtin_amdgcn_s_setprio(3);        // the serial chain must win issue arbitration on its SIMD
-            uint32_t dr_next = drw[lane < PG ? lane : 0], badw = 0u, last_rec = 0u;
+            // running LDS pointers (one add per step each); drw has one spare row, so the prefetch of step tl + 1 needs no clamp
+            const uint32_t *drp = drw + (lane < PG ? lane : 0);
+            uint32_t *rgp = ring + (lane < PG ? lane : 0);
+            uint32_t dr_next = *drp, badw = 0u, last_rec = 0u;
             // the whole loop sits inside the lane predicate: one exec set-up per chunk instead of an if / else per step
             if (lg_active) for (int tl = 0; tl < len; ++tl) {
                 {
                     const uint32_t dr = dr_next;
-                    dr_next = drw[min(tl + 1, len - 1) * PG + lane];      // next step's word: its LDS latency leaves the chain
+                    drp += PG;
+                    dr_next = *drp;                                       // next step's word: its LDS latency leaves the chain
                     badw |= dr;                                           // bit 20: the reference raises on this action
                     s.step_move += 1;
                     s.m6 = s.m6 == 5 ? 0 : s.m6 + 1;
@@ -1355,7 +1359,8 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
                         s.ax = 3; s.ay = 15; s.step_count = 0;
                     }
                     last_rec = rec;
-                    ring[tl * PG + lane] = rec;
+                    *rgp = rec;
+                    rgp += PG;
                 }
             }
             if (lg_active) {                                              // what the loop left for the end of the chunk
@@ -1695,7 +1700,7 @@ void launch_variant(const tw_engine *e, const Params &p, hipStream_t st) {
 }
 
 constexpr int PIPE_MIN_T = 8;
-constexpr size_t PIPE_LDS_BYTES = (size_t)(PWAVES * ENV_WORDS + PCH * PG_MAX + PG_MAX * REC + 4 + PCH * PG_MAX) * 4;   // ~117 KB
+constexpr size_t PIPE_LDS_BYTES = (size_t)(PWAVES * ENV_WORDS + PCH * PG_MAX + PG_MAX * REC + 4 + (PCH + 1) * PG_MAX) * 4;   // ~117 KB; drw has a spare row
 
 int launch_sequential(const tw_engine *e, const Params &p, hipStream_t st) {
     switch (pick_envs_per_wave(e)) {
