@@ -31,7 +31,10 @@ extern "C" {
 /* type, colour, state: uint8[N][H*W] (state nullable); agent_x, agent_y, agent_dir: int32[N] (dir 0 right, 1 down,
  * 2 left, 3 up); carrying: uint8[N][3] = WorldObj.encode() of the carried object, type 0 = nothing (nullable);
  * image: uint8[N][image_pitch] with the [V][V][3] observation (indexed [i][j][channel] like obs["image"]) in the
- * first V*V*3 bytes of each row (image_pitch 0 = dense); vis_mask: uint8[N][V*V] indexed [i][j] (nullable). */
+ * first V*V*3 bytes of each row (image_pitch 0 = dense); vis_mask: uint8[N][V*V] indexed [i][j] (nullable).
+ * The planes are read as 4-byte-aligned words: the words that hold the first and the last byte of a plane array are
+ * read whole, i.e. up to 3 bytes before its start / after its end inside the same aligned word (always inside the
+ * caller's allocation when that starts and ends on 4-byte boundaries, as hipMalloc / torch allocations do). */
 int mg_gen_obs(const uint8_t *type, const uint8_t *colour, const uint8_t *state, int n_envs, int width, int height,
                const int32_t *agent_x, const int32_t *agent_y, const int32_t *agent_dir, const uint8_t *carrying,
                int view_size, int see_through_walls, uint8_t *image, int image_pitch, uint8_t *vis_mask, void *stream);
