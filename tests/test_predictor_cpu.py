@@ -75,3 +75,21 @@ def check_pred_states_and_heads(device, tol):
 
 def test_pred_states_and_heads_match_reference():
     check_pred_states_and_heads("cpu", 1.0)
+
+
+def test_update_reads_transition_0_of_the_window_records():
+    """ppo_predictor._unpack: of a 9-frame window record the update trains on frames 0..4 and slot 0 of a / r / a_logp
+    (PPO_Predictor.py:126-155); checked on the window buffer the reference itself updated on (predictor_update.npz)."""
+    from twoarmy_amd.soa.env_buffer import Buffer_gridworld
+    g = dict(np.load(GOLDEN + "/predictor_update.npz"))
+    dt = Buffer_gridworld.window_dtype(17)
+    buf = np.zeros(g["buf_s"].shape[0], dtype=dt)
+    for k in dt.names:
+        buf[k] = g["buf_" + k]
+    s, p, a, goal, r, old = _agent()()._unpack(buf, torch.device("cpu"))
+    n = len(buf)
+    assert s.shape == (n, 5, 289) and p.shape == (n, 5, 2) and a.shape == (n,) and r.shape == (n,) and old.shape == (n, 1)
+    assert np.array_equal(s.numpy(), buf["s"][:, :5].astype(np.float32)) and np.array_equal(p.numpy(), buf["p"][:, :5].astype(np.float32))
+    assert np.array_equal(a.numpy(), buf["a"][:, 0, 0]) and np.array_equal(r.numpy(), buf["r"][:, 0, 0].astype(np.float32))
+    assert np.array_equal(old.numpy()[:, 0], buf["a_logp"][:, 0, 0].astype(np.float32)) and np.array_equal(goal.numpy(), buf["g"].astype(np.float32))
+    assert a.dtype == torch.int32 and int((buf["r"][:, 0, 0] == 0.9).sum()) >= 1          # hindsight records are among them
