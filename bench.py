@@ -50,17 +50,26 @@ def algorithmic_bytes_per_env_step(view, rollout_t, matrix_bytes=289 * 4):
     return per_step + per_launch / float(rollout_t)
 
 
-def traffic_from_profile(variant, n_envs, rollout_t, view):
-    """HBM bytes per launch of the dominant kernel from the committed PMC profile of the SAME configuration
-    (a bench run cannot profile itself); None when the configuration differs from the profiled one."""
+def traffic_from_profile(variant, n_envs, rollout_t, view, build_id=None, profiles_dir=None):
+    """HBM bytes per launch of the dominant kernel from the committed PMC profile of the SAME configuration AND the
+    SAME build (a bench run cannot profile itself): the newest profiles/r*_traffic.json whose recorded `build_id`
+    equals the running library's tw_build_id().  (None, reason) when the configuration differs from the profiled one
+    or every committed profile was taken on another build -- a stale number is never reported.
+    tools/gpu_traffic.sh re-takes the profile (two rocprofv3 --pmc passes) for the current build."""
     if not (variant == "v6" and n_envs == 4096 and rollout_t == 128 and view == 17):
         return None, None
-    for name in ("r02_traffic.json", "r01_traffic.json"):
-        path = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(path):
-            with open(path) as f:
-                return json.load(f)["traffic_bytes_per_launch"], "profiles/" + name
-    return None, None
+    pdir = profiles_dir or os.path.join(ROOT, "profiles")
+    if build_id is None:
+        from twoarmy_amd import _lib
+        build_id = _lib.lib().tw_build_id().decode()
+    stale = []
+    for name in sorted((f for f in os.listdir(pdir) if f.endswith("_traffic.json")), reverse=True):
+        with open(os.path.join(pdir, name)) as f:
+            prof = json.load(f)
+        if prof.get("build_id") == build_id:
+            return prof["traffic_bytes_per_launch"], "profiles/%s (build %s)" % (name, build_id)
+        stale.append("%s: build %s" % (name, prof.get("build_id", "not recorded")))
+    return None, "no counter profile of build %s (stale: %s); run tools/gpu_traffic.sh" % (build_id, "; ".join(stale))
 
 
 def usable_cores():
@@ -121,6 +130,9 @@ def build_parser():
     ap.add_argument("--slab-check", type=int, default=3,
                     help="rollout mode: time the kernel into this many freshly allocated engine slabs at set-up and report "
                          "the values (evidence that placement no longer matters; nothing is selected); 1 = skip")
+    ap.add_argument("--regions", type=int, default=0,
+                    help="rollout/step mode: number of timed regions of --steps launches each (0 = auto: >= 25 and >= 100 ms "
+                         "of GPU time in total); the median region is reported")
     ap.add_argument("--torch-outputs", action="store_true",
                     help="diagnostic: outputs from torch's caching allocator instead of the engine's slab")
     ap.add_argument("--matrix-codes", action="store_true",
@@ -230,6 +242,78 @@ def max_over_ranks(dt, dev, world):
     return float(t.item())
 
 
+def max_over_ranks_vec(dts, dev, world):
+    """Element-wise MAX over ranks of a list of region times (one all-reduce)."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return list(dts)
+    on_gpu = dist.get_backend() == "nccl"
+    t = torch.tensor(dts, dtype=torch.float64, device=dev if on_gpu else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(x) for x in t.tolist()]
+
+
+def allreduce_alone_ms(bucket, dev, iters=20):
+    """The bucket's collectives with nothing to overlap: `iters` x (one all-reduce per parameter group + the scale),
+    events on the compute stream (wall clock on CPU tensors).  Every rank calls this the same number of times."""
+    import torch
+    if not bucket.active():
+        return None
+    was, bucket.timing = bucket.timing, False
+    bucket()
+    if dev is not None:
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        bucket()
+    if dev is not None:
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / iters
+    else:
+        ms = (time.perf_counter() - t0) * 1e3 / iters
+    bucket.timing = was
+    bucket.n_reduces -= (iters + 1) * len(bucket.parts)
+    return ms
+
+
+def grad_bucket_record(nparam, n_reduces, exposed, alone_ms, opt_steps, update_s, n_copied):
+    """config.grad_bucket of a --mode ppo line: what the gradient exchange cost per optimiser step."""
+    step_ms = update_s * 1e3 / max(1, opt_steps) * 1.0
+    mean_exposed = (sum(exposed) / len(exposed)) if exposed else None
+    return {"floats": nparam, "bytes": 4 * nparam, "allreduces_issued": n_reduces, "optimiser_steps_per_iteration": opt_steps,
+            "layout": "zero-copy: .grad views into one flat fp32 buffer, one all-reduce per network (actor's overlaps the "
+                      "critic's backward), one scale kernel",
+            "gradients_copied_into_bucket": n_copied,
+            "ms_per_allreduce": alone_ms,
+            "ms_per_allreduce_what": "both networks' all-reduces + scale, back to back with nothing to overlap (20 repeats)",
+            "ms_exposed_per_optimiser_step_mean": mean_exposed,
+            "ms_exposed_per_optimiser_step_max": max(exposed) if exposed else None,
+            "ms_exposed_what": "end of the critic's backward -> gradients averaged, on the compute stream",
+            "ms_per_optimiser_step": step_ms,
+            "share_of_optimiser_step": (mean_exposed / step_ms) if (mean_exposed is not None and step_ms > 0) else None}
+
+
+def slab_backing_of_ranks(mine, dev, world):
+    """Every rank's output-slab backing, gathered on all ranks; ranks that disagree are a hard error (the headline
+    depends on the placement: a silent hipMalloc fallback on some ranks must not hide in an aggregate)."""
+    import torch.distributed as dist
+    if world == 1:
+        return {"per_rank": [mine], "agree": True}
+    got = [None] * world
+    dist.all_gather_object(got, mine)
+    agree = all(g == got[0] for g in got)
+    if not agree:
+        if dist.get_rank() == 0:
+            print("bench.py: ranks disagree on the output slab backing: %s" % got, file=sys.stderr, flush=True)
+        dist.barrier()
+        raise SystemExit(5)
+    return {"per_rank": got, "agree": True}
+
+
 def fill_ceiling_gbs(dev):
     """Write-only ceiling of this very box (a measured device ceiling beside the vendor peak)."""
     import torch
@@ -283,21 +367,42 @@ def run_engine_mode(args, rank, world, dev, coll):
             if rollout:
                 eng.rollout(T, out, actions=actions[i % n_act], autoreset=True, policy_idx=True)
             else:
-                eng.step(actions[i, 0], out, autoreset=True, policy_idx=True)
+                eng.step(actions[i % n_act, 0], out, autoreset=True, policy_idx=True)
 
     run(0, W)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    sync_all(dev, world)
-    t0 = time.perf_counter()
-    e0.record()                     # torch's current stream == the stream handed to tw_rollout (engine._stream)
-    run(W, K)
-    e1.record()
-    sync_all(dev, world)
-    dt = time.perf_counter() - t0
-    ev_ms = e0.elapsed_time(e1)
-    dt = max_over_ranks(dt, dev, world)
+    # clocks: at least ~50 ms of launches before the first timed region (a 4 ms region right after set-up ran 3-8 % off)
+    ew0, ew1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ew0.record()
+    run(0, 8)
+    ew1.record()
+    torch.cuda.synchronize()
+    est_ms = max(ew0.elapsed_time(ew1) / 8.0, 1e-3)
+    warm_launches = 8 + int(50.0 / est_ms) + 1
+    run(0, warm_launches - 8)
+    # R timed regions of exactly K launches each, every one bracketed by barrier + synchronize on both sides; the line
+    # reports the MEDIAN region (value, ms_per_step, roofline.kernel_ms) and the spread of all of them
+    R = args.regions if args.regions > 0 else max(25, int(100.0 / (K * est_ms)) + 1)
+    wall_s, ev_ms_all = [], []
+    for r_ in range(R):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sync_all(dev, world)
+        t0 = time.perf_counter()
+        e0.record()                 # torch's current stream == the stream handed to tw_rollout (engine._stream)
+        run(W + r_ * K, K)
+        e1.record()
+        sync_all(dev, world)
+        wall_s.append(time.perf_counter() - t0)
+        ev_ms_all.append(e0.elapsed_time(e1))
+    wall_s = max_over_ranks_vec(wall_s, dev, world)
+    order = sorted(range(R), key=lambda i: wall_s[i])
+    med = order[R // 2]
+    dt, ev_ms = wall_s[med], ev_ms_all[med]
     del slabs
 
+    layout = getattr(out["matrix"], "_tw_layout", None)
+    mine = "torch caching allocator" if layout is None else ("hipMalloc" if "hipMalloc" in layout else "2 MiB mapped chunks") + \
+        (" (FALLBACK: torch could not alias the mapped slab)" if getattr(out["matrix"], "_tw_fallback", False) else "")
+    backing = slab_backing_of_ranks(mine, dev, world)
     bpe = algorithmic_bytes_per_env_step(V, T, 289 if args.matrix_codes else 289 * 4)
     k_ms = ev_ms / K                                    # device time per launch, same K launches as `value`
     bytes_per_launch = bpe * N * T
@@ -325,6 +430,7 @@ def run_engine_mode(args, rank, world, dev, coll):
                    "collective": coll,
                    "output_buffers": "torch caching allocator, two streams" if (args.torch_outputs or placement_ms or not rollout)
                                      else "engine slab (tw_alloc_outputs): %s" % getattr(out["matrix"], "_tw_layout", "?"),
+                   "slab_backing": backing,
                    "output_placement_probe_ms": placement_ms,
                    "slab_check_ms": None if slab_check_ms is None else {
                        "what": "untimed set-up: kernel ms per launch into %d freshly allocated engine slabs; no selection, "
@@ -335,7 +441,12 @@ def run_engine_mode(args, rank, world, dev, coll):
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "tw_pipe_kernel" if pipelined else "tw_rollout_kernel",
                      "kernel_ms": k_ms, "launches_timed": K, "timed_region": "the same K launches as `value` "
-                     "(events on the launch stream)", "wall_over_event": dt * 1e3 / ev_ms,
+                     "(events on the launch stream): the median of `regions` back-to-back regions of K launches",
+                     "regions": R, "gpu_ms_timed_total": sum(ev_ms_all), "clock_warm_launches": warm_launches,
+                     "kernel_ms_samples": {"min": min(ev_ms_all) / K, "median": sorted(ev_ms_all)[R // 2] / K,
+                                           "max": max(ev_ms_all) / K, "max_over_min": max(ev_ms_all) / min(ev_ms_all)},
+                     "region_wall_ms_samples": {"min": min(wall_s) * 1e3, "median": dt * 1e3, "max": max(wall_s) * 1e3},
+                     "wall_over_event": dt * 1e3 / ev_ms,
                      "algorithmic_bytes_per_env_step": bpe, "bytes_per_launch": bytes_per_launch,
                      "survey_bytes_per_env_step": 2690, "us_per_env_batch_step": k_ms * 1e3 / T,
                      "launches_per_env_batch_step": 1.0 / T, "measured_fill_ceiling_GBs": fill_gbs,
@@ -373,23 +484,17 @@ def run_ppo_mode(args, rank, world, dev, coll):
     if not args.nchw:
         agent.use_nhwc()
     twdist.broadcast_parameters([agent.actor, agent.critic])
-    sync_ms = []
     bucket = None
     if world > 1:
-        bucket = twdist.GradBucket(list(agent.actor.parameters()) + list(agent.critic.parameters()))
-
-        def timed_sync(_params=None):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            bucket()
-            b.record()
-            sync_ms.append((a, b))
-        agent.grad_sync = timed_sync if dist.get_backend() == "nccl" else bucket
+        # zero-copy bucket: gradients are views into one flat buffer, the actor's all-reduce overlaps the critic's backward
+        bucket = twdist.GradBucket([list(agent.actor.parameters()), list(agent.critic.parameters())])
+        bucket.timing = dev is not None
+        agent.grad_sync = bucket
     eng = TwoarmyEngine(variant, N, 17, device=dev, seed=SEED, env_id0=rank * N)
     tr = VecPPOTrainer(agent, eng, rollout_steps=T, minibatch=args.minibatch, frame_codes=args.matrix_codes)
     tr.time_phases = True
     tr.use_graph = not args.predictor and (args.graph == "on" or (args.graph == "auto" and N <= 512))
-    roll_s, upd_s, her_n = [], [], []
+    roll_s, upd_s, her_n, val_rows = [], [], [], []
 
     def iteration(timed):
         torch.cuda.synchronize()
@@ -405,24 +510,32 @@ def run_ppo_mode(args, rank, world, dev, coll):
         t2 = time.perf_counter()
         tr.carry_over()
         if timed:
-            roll_s.append(t1 - t0); upd_s.append(t2 - t1); her_n.append(h)
+            roll_s.append(t1 - t0); upd_s.append(t2 - t1); her_n.append(h); val_rows.append(tr.value_rows)
 
     for _ in range(W):
         iteration(False)
-    del sync_ms[:]
+    if bucket is not None:
+        del bucket.events[:]
+        bucket.n_reduces = 0
     sync_all(dev, world)
     t0 = time.perf_counter()
     for _ in range(K):
         iteration(True)
     sync_all(dev, world)
     dt = max_over_ranks(time.perf_counter() - t0, dev, world)
-    ar_ms = [a.elapsed_time(b) for a, b in sync_ms]
+    ar_exposed = bucket.exposed_ms() if bucket is not None else []
+    n_reduces = bucket.n_reduces if bucket is not None else 0
+    ar_alone = allreduce_alone_ms(bucket, dev) if bucket is not None else None
+    backing = slab_backing_of_ranks("n/a (ppo mode: torch tensors)", dev, world)
     if rank != 0:
         return None
     S = N * T
     samples = S + sum(her_n) / max(1, len(her_n))
     opt_steps = args.k_epochs * -(-int(samples) // args.minibatch)
-    flop_upd = samples * FWD_FLOP_PER_SAMPLE_PER_NET * (2 + args.k_epochs * 3 * 2)
+    # critic forwards of the target pass as actually issued (V(s') = V(s of the next step) reuse: ~1 per sample instead of
+    # the reference's 2, padding rows included), then K epochs x 2 nets x (fwd + 2x bwd) over every sample
+    target_rows = sum(val_rows) / max(1, len(val_rows))
+    flop_upd = FWD_FLOP_PER_SAMPLE_PER_NET * (target_rows + samples * args.k_epochs * 3 * 2)
     r, u = sum(roll_s) / K, sum(upd_s) / K
     nparam = sum(p.numel() for p in list(agent.actor.parameters()) + list(agent.critic.parameters()) if p.requires_grad)
     return {
@@ -441,34 +554,74 @@ def run_ppo_mode(args, rank, world, dev, coll):
                    "her_records_per_iteration": sum(her_n) / max(1, len(her_n)),
                    "parallelism": "env-sharded x%d, one gradient-bucket all-reduce per optimiser step" % world,
                    "collective": coll,
-                   "grad_bucket": {"floats": nparam, "bytes": 4 * nparam, "allreduces_timed": len(ar_ms),
-                                   "ms_per_allreduce_mean": (sum(ar_ms) / len(ar_ms)) if ar_ms else None,
-                                   "ms_per_allreduce_min": min(ar_ms) if ar_ms else None,
-                                   "includes": "flatten + all_reduce + divide + scatter back (dist.GradBucket)"}},
+                   "slab_backing": backing,
+                   "grad_bucket": grad_bucket_record(nparam, n_reduces, ar_exposed, ar_alone, opt_steps * K, u,
+                                                     None if bucket is None else bucket.n_copied)},
         "roofline": {"bound": "mfma", "achieved": flop_upd / u / 1e12, "peak": 157.3 if args.amp == "fp32" else 2500.0,
                      "unit": "TFLOP/s", "frac": flop_upd / u / 1e12 / (157.3 if args.amp == "fp32" else 2500.0),
-                     "traffic": None, "what": "update phase: algorithmic conv/linear flops (47.5 MFLOP fwd per sample per "
-                     "net; targets 2 fwd + K x (fwd + 2x bwd) x 2 nets) / update wall time",
+                     "traffic": None, "what": "update phase: actor/critic conv/linear flops (47.5 MFLOP fwd per sample per "
+                     "net; target pass = %.2f critic fwd per sample as issued, + K x (fwd + 2x bwd) x 2 nets) / update wall "
+                     "time%s" % (target_rows / max(1.0, samples), "; the frozen world model's flops are NOT counted"
+                                 if args.predictor else ""),
+                     "target_forward_rows": target_rows,
                      "rollout_TFLOPs": S * FWD_FLOP_PER_SAMPLE_PER_NET / r / 1e12},
     }
 
 
 def run_rehearsal(args, rank, world, dev, coll):
-    """Launcher and process-group plumbing without the engine (CPU-only hosts): W + K empty steps."""
+    """Launcher and process-group plumbing without the engine (CPU-only hosts, gloo): the per-rank slab-backing gather,
+    and W + K "steps" that are optimiser steps of two small CPU networks through the same two-group gradient bucket
+    protocol as the PPO loop (ranks take different numbers of local steps and agree on the maximum)."""
+    import torch
+    from twoarmy_amd import dist as twdist
+    from twoarmy_amd.soa.ppo_vec import agree_on_steps
     K = args.steps if args.steps is not None else 2
     W = args.warmup if args.warmup is not None else 1
+    mine = "rehearsal"
+    if os.environ.get("TW_REHEARSE_ODD_RANK", "") == str(rank):
+        mine = "hipMalloc"                          # test hook: one rank reports another backing -> the run must abort
+    backing = slab_backing_of_ranks(mine, None, world)
+    torch.manual_seed(SEED + rank)
+    nets = [torch.nn.Linear(8, 4), torch.nn.Linear(8, 1)]
+    twdist.broadcast_parameters(nets)
+    bucket = twdist.GradBucket([list(n.parameters()) for n in nets])
+    opts = [torch.optim.Adam(n.parameters(), 1e-3) for n in nets]
+    n_steps = agree_on_steps(W + K + (rank % 3), "cpu") - W          # ranks ask for different counts; all take the max
+
+    def step():
+        x = torch.randn(16, 8)
+        bucket.zero()
+        nets[0](x).square().mean().backward()
+        bucket.reduce_async(0)
+        nets[1](x).square().mean().backward()
+        bucket.reduce_async(1)
+        bucket.finish()
+        for o in opts:
+            o.step()
+    for _ in range(W):
+        step()
     sync_all(None, world)
     t0 = time.perf_counter()
-    for _ in range(K):
-        pass
+    for _ in range(n_steps):
+        step()
     sync_all(None, world)
     dt = max_over_ranks(time.perf_counter() - t0, None, world)
+    chk = torch.cat([p.detach().reshape(-1) for n in nets for p in n.parameters()]).double().sum().reshape(1)
+    lo, hi = chk.clone(), chk.clone()
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
     if rank != 0:
         return None
     return {"metric": "env-steps/sec", "value": 0.0, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "ms_per_step": dt / max(1, K) * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
             "data": "rehearsal", "config": {"workload": "launcher rehearsal: no engine, nothing measured",
-                                            "collective": coll}}
+                                            "collective": coll, "slab_backing": backing,
+                                            "grad_bucket": {"allreduces_issued": bucket.n_reduces,
+                                                            "optimiser_steps": W + n_steps,
+                                                            "gradients_copied_into_bucket": bucket.n_copied,
+                                                            "replicas_identical": bool(lo.item() == hi.item())}}}
 
 
 def main(argv=None):

@@ -68,6 +68,7 @@ _SIGS = {
     "tw_view_size": (C.c_int, [_vp]),
     "tw_last_hip_error": (C.c_int, []),
     "tw_version": (C.c_char_p, []),
+    "tw_build_id": (C.c_char_p, []),
     "tw_last_error_message": (C.c_char_p, []),
     "tw_alloc_outputs": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(TwOutputs)]),
     "tw_free_outputs": (C.c_int, [C.POINTER(TwOutputs)]),

@@ -2030,7 +2030,8 @@ int slab_alloc(int device, size_t bytes, int backing, Slab &s) {
             if (is_mapped[i]) (void)hipMemUnmap((char *)s.base + i * chunk, chunk);
         for (auto h : s.handles) (void)hipMemRelease(h);
         s.handles.clear(); s.slots.clear();
-        (void)hipMemAddressFree(s.base, s.bytes);
+        // the range stays reserved, like in slab_release: a freed range that comes back from a later reserve is the
+        // pattern that lost rows (the caller falls back to hipMalloc right after this)
         s.base = nullptr;
         return hip_fail(err);
     }
@@ -2101,7 +2102,11 @@ int tw_n_envs(const tw_engine *e) { return e ? e->n_envs : TW_E_ARG; }
 int tw_view_size(const tw_engine *e) { return e ? e->view : TW_E_ARG; }
 int tw_last_hip_error(void) { return g_last_hip_error; }
 const char *tw_last_error_message(void) { return g_last_error_msg; }
-const char *tw_version(void) { return "twoarmy-hip 0.2 (gfx950)"; }
+const char *tw_version(void) { return "twoarmy-hip 0.3 (gfx950)"; }
+#ifndef TW_BUILD_ID
+#define TW_BUILD_ID "unknown"
+#endif
+const char *tw_build_id(void) { return TW_BUILD_ID; }
 
 int tw_time_rollout(tw_engine *e, int T, const int32_t *actions, uint8_t *obs, int obs_pitch, float *state_matrix,
                     int mat_pitch, float *pos, float *reward, uint8_t *terminated, uint8_t *truncated, int flags,

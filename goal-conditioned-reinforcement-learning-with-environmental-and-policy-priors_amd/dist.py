@@ -1,6 +1,6 @@
 """Multi-GPU glue: env batches shard across ranks (disjoint env-id ranges, no data-path exchange); the only
-collective is ONE all-reduce of the flattened fp32 gradient bucket of actor + critic per optimiser step
-(2 515 206 floats ~ 10 MB), averaged over ranks.  backend "nccl" is RCCL over xGMI on ROCm; the same code
+collective is the all-reduce of the flattened fp32 gradient bucket of actor + critic per optimiser step
+(2 515 206 floats ~ 10 MB: the actor's half goes out while the critic's backward runs), averaged over ranks.  backend "nccl" is RCCL over xGMI on ROCm; the same code
 runs on "gloo" for the CPU tests."""
 import os
 
@@ -36,35 +36,113 @@ def shard_range(total_envs, rank, world):
 
 
 class GradBucket:
-    """Flattens the gradients of `params` into one persistent fp32 buffer and all-reduces it once."""
+    """Zero-copy gradient bucket: ONE persistent flat fp32 buffer, every parameter's `.grad` is a VIEW into it
+    (as_strided with the parameter's own strides, so channels-last conv weights get channels-last gradients), so an
+    optimiser step is: `zero()` (one fill kernel), the backward passes accumulate straight into the bucket,
+    `reduce_async(g)` per parameter group (one all-reduce each, on the backend's own stream: the actor's collective
+    runs while the critic's backward is still computing), `finish()` (wait + one scale kernel).  No per-parameter
+    copy kernel anywhere.
 
-    def __init__(self, params):
-        self.params = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
-        self.numel = n
+    groups: a list of parameter lists -- one all-reduce per group, laid out back to back in the flat buffer -- or a flat
+    parameter list (one group).  PPO: [actor parameters, critic parameters] = 1 258 629 + 1 256 577 floats.
+
+    Legacy use (`bucket()` after an optimiser's own `zero_grad()` detached the views): gradients that are not views of
+    the bucket any more are copied in and re-attached, then everything is reduced -- correct, just not copy-free."""
+
+    def __init__(self, groups):
+        groups = list(groups)
+        if groups and isinstance(groups[0], torch.nn.Parameter):
+            groups = [groups]
+        self.groups = [[p for p in g if p.requires_grad] for g in groups]
+        self.params = [p for g in self.groups for p in g]
+        self.numel = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self.views, self.parts = [], []
+        off = 0
+        for g in self.groups:
+            lo = off
+            for p in g:
+                n = p.numel()
+                dense = p.is_contiguous() or p.is_contiguous(memory_format=torch.channels_last)
+                v = self.flat[off:off + n].as_strided(p.size(), p.stride()) if dense and p.dim() > 0 \
+                    else self.flat[off:off + n].view(p.shape)
+                self.views.append(v)
+                off += n
+            self.parts.append(self.flat[lo:off])
+        self._work = []
+        self.n_reduces = 0                      # all-reduce calls issued (tests / bench bookkeeping)
+        self.n_copied = 0                       # gradients that had to be copied in (0 on the zero-copy path)
+        self.timing = False                     # record (last reduce_async -> finish) event pairs on the current stream
+        self.events = []
+        self._ev0 = None
+        self.attach()
+
+    # ---- zero-copy protocol
+    def attach(self):
+        """Point every parameter's .grad at its slice of the bucket (keeps the current contents of the bucket)."""
+        for p, v in zip(self.params, self.views):
+            if p.grad is not v:
+                p.grad = v
+
+    def zero(self):
+        """Replaces optimizer.zero_grad(): one fill of the flat buffer, gradients stay views into it."""
+        self.attach()
+        self.flat.zero_()
+
+    def active(self):
+        return dist.is_initialized() and dist.get_world_size() > 1
+
+    def _adopt(self):
+        """Gradients that are no views of the bucket (someone called zero_grad(set_to_none=True) and backward made
+        fresh tensors, or left None): copy / zero them into place and re-attach."""
+        for p, v in zip(self.params, self.views):
+            if p.grad is v:
+                continue
+            if p.grad is None:
+                v.zero_()
+            else:
+                v.copy_(p.grad)
+                self.n_copied += 1
+            p.grad = v
+
+    def reduce_async(self, group=None):
+        """Start the all-reduce of one parameter group (None: all of them, one collective per group).  Returns at once;
+        the collective is ordered behind everything already enqueued on the current stream."""
+        if not self.active():
+            return
+        self._adopt()
+        if self.timing and self.flat.is_cuda:
+            # (re)recorded by every call: the pair measures from the LAST reduce_async of a step, i.e. from the end of
+            # the last backward, to the end of finish() -- the part of the collectives no backward overlaps with
+            self._ev0 = torch.cuda.Event(enable_timing=True)
+            self._ev0.record()
+        for k in (range(len(self.parts)) if group is None else [group]):
+            self._work.append(dist.all_reduce(self.parts[k], op=dist.ReduceOp.SUM, async_op=True))
+            self.n_reduces += 1
+
+    def finish(self):
+        """Wait for the collectives started by reduce_async and turn the sums into means (one kernel)."""
+        if not self._work:
+            return
+        for w in self._work:
+            w.wait()
+        self._work = []
+        self.flat.mul_(1.0 / dist.get_world_size())
+        if self._ev0 is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.events.append((self._ev0, e1))
+            self._ev0 = None
+
+    def exposed_ms(self):
+        """ms between the last reduce_async of a step and the end of finish() on the compute stream, per step
+        (what the collectives add to an optimiser step beyond the backward they overlap with)."""
+        return [a.elapsed_time(b) for a, b in self.events]
 
     def __call__(self, _params=None):
-        if not dist.is_initialized() or dist.get_world_size() == 1:
-            return
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                self.flat[off:off + n].zero_()
-            else:
-                self.flat[off:off + n].copy_(p.grad.reshape(-1))
-            off += n
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        self.flat.div_(dist.get_world_size())
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                p.grad = self.flat[off:off + n].view_as(p).clone()
-            else:
-                p.grad.copy_(self.flat[off:off + n].view_as(p))
-            off += n
+        self.reduce_async(None)
+        self.finish()
 
 
 def broadcast_parameters(modules, src=0):

@@ -210,11 +210,20 @@ class TwoarmyEngine:
         N, V = self.num_envs, self.view_size
         flags = TW_F_MATRIX_CODE if matrix_codes else 0
         owner = _OutputSlab(self, 1 if T is None else T, flags)
+        fell_back = False
         try:
             owner.tensor(min(owner.out.obs, owner.out.matrix), 16, torch.uint8)
-        except _lib.TwoarmyLibraryError:
+        except _lib.TwoarmyLibraryError as exc:
             # a mapped slab torch cannot wrap in place (seen nowhere so far; multi-GPU ranks are the untested case):
-            # the same layout from plain hipMalloc memory, whose pointer attributes torch certainly understands
+            # the same layout from plain hipMalloc memory, whose pointer attributes torch certainly understands.
+            # Never silent: a warning here, `_tw_fallback` on the tensors, `config.slab_backing` in bench.py's line
+            # (ranks that disagree abort the run), TW_SLAB_STRICT=1 turns it into an error.
+            import os
+            import warnings
+            if os.environ.get("TW_SLAB_STRICT", "0") == "1":
+                raise
+            warnings.warn("engine slab: falling back to hipMalloc backing (%s)" % exc, RuntimeWarning)
+            fell_back = True
             owner = _OutputSlab(self, 1 if T is None else T, flags | TW_F_SLAB_HIPMALLOC)
         o = owner.out
         TN = (1 if T is None else T) * N
@@ -233,6 +242,7 @@ class TwoarmyEngine:
             obs = rec[..., MAT_PITCH * 4:MAT_PITCH * 4 + nb].view(lead + (V, V, 3))
         m._tw_layout = ("%d-byte records (image | codes)" % rb if matrix_codes else "%d-byte records (matrix | image)" % rb) + \
             (", hipMalloc" if o.backing == 0 else ", 2 MiB mapped chunks")
+        m._tw_fallback = fell_back
         return dict(obs=obs, matrix=m,
                     pos=owner.tensor(o.pos, TN * 8, torch.float32).view(lead + (2,)),
                     reward=owner.tensor(o.reward, TN * 4, torch.float32).view(lead),

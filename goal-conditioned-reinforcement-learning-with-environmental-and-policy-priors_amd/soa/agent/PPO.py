@@ -84,7 +84,7 @@ class PPO:
         self.gae_lambda = 0.0
         self.use_done_mask = False
         self.normalize_adv = False
-        self.grad_sync = None                      # callable(list_of_params) for multi-GPU (dist.py)
+        self.grad_sync = None                      # multi-GPU: dist.GradBucket([actor params, critic params]) (or any callable(params))
         self.amp_dtype = None                      # torch.bfloat16: conv/linear GEMMs on bf16 MFMA (opt-in; fp32 = parity)
 
     # ------------------------------------------------------------------ acting
@@ -172,12 +172,25 @@ class PPO:
         value = self.critic_value(x0, p0, g)
         action_loss, value_loss = ppo_ops.ppo_losses(probs, value, a, old_logp, adv, target_v,
                                                      clip=self.clip_param, ent_coef=self.entropy_coef, n_valid=n_valid)
-        self.optimizer_actor.zero_grad()
-        self.optimizer_critic.zero_grad()
-        action_loss.backward()
-        value_loss.backward()
-        if self.grad_sync is not None:
-            self.grad_sync(list(self.actor.parameters()) + list(self.critic.parameters()))
+        bucket = self.grad_sync if hasattr(self.grad_sync, "reduce_async") else None
+        if bucket is not None:
+            # multi-GPU, dist.GradBucket([actor params, critic params]): gradients are views into one flat buffer; the
+            # actor's all-reduce is in flight while the critic's backward computes
+            split = len(bucket.parts) == 2               # [actor, critic]; a one-group bucket is reduced after both
+            bucket.zero()
+            action_loss.backward()
+            if split:
+                bucket.reduce_async(0)
+            value_loss.backward()
+            bucket.reduce_async(1 if split else None)
+            bucket.finish()
+        else:
+            self.optimizer_actor.zero_grad()
+            self.optimizer_critic.zero_grad()
+            action_loss.backward()
+            value_loss.backward()
+            if self.grad_sync is not None:
+                self.grad_sync(list(self.actor.parameters()) + list(self.critic.parameters()))
         if self.use_grad_clip:
             torch.nn.utils.clip_grad_norm_(self.actor.parameters(), 0.5)
             torch.nn.utils.clip_grad_norm_(self.critic.parameters(), 0.5)

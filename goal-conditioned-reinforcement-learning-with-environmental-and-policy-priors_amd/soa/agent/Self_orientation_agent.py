@@ -149,10 +149,16 @@ class self_orinetation_agent(ppo_predictor):
         nll = (-Categorical(probs=p0).log_prob(cls[:, 0]).view(-1, 1)
                - Categorical(probs=p1).log_prob(cls[:, 1]).view(-1, 1))
         loss = nll.mean() if n_valid is None else nll[:n_valid].sum() / float(n_valid)
-        self.optimizer_agent_position_preditor.zero_grad()
-        loss.backward()
-        if self.grad_sync_orient is not None:
-            self.grad_sync_orient(list(self.agent_position_preditor.parameters()))
+        bucket = self.grad_sync_orient if hasattr(self.grad_sync_orient, "reduce_async") else None
+        if bucket is not None:                       # dist.GradBucket: gradients accumulate straight into the bucket
+            bucket.zero()
+            loss.backward()
+            bucket()
+        else:
+            self.optimizer_agent_position_preditor.zero_grad()
+            loss.backward()
+            if self.grad_sync_orient is not None:
+                self.grad_sync_orient(list(self.agent_position_preditor.parameters()))
         if self.use_grad_clip:
             torch.nn.utils.clip_grad_norm_(self.agent_position_preditor.parameters(), 0.5)
         self.optimizer_agent_position_preditor.step()
@@ -163,11 +169,15 @@ class self_orinetation_agent(ppo_predictor):
     def orientation_idle_step(self):
         """Optimiser step of a rank that has no orientation sample this update: zero local gradients, the same
         all-reduce and Adam step as its peers, so replicas stay identical and no collective is skipped."""
-        self.optimizer_agent_position_preditor.zero_grad()
-        for p in self.agent_position_preditor.parameters():
-            p.grad = torch.zeros_like(p)
-        if self.grad_sync_orient is not None:
-            self.grad_sync_orient(list(self.agent_position_preditor.parameters()))
+        if hasattr(self.grad_sync_orient, "reduce_async"):
+            self.grad_sync_orient.zero()
+            self.grad_sync_orient()
+        else:
+            self.optimizer_agent_position_preditor.zero_grad()
+            for p in self.agent_position_preditor.parameters():
+                p.grad = torch.zeros_like(p)
+            if self.grad_sync_orient is not None:
+                self.grad_sync_orient(list(self.agent_position_preditor.parameters()))
         if self.use_grad_clip:
             torch.nn.utils.clip_grad_norm_(self.agent_position_preditor.parameters(), 0.5)
         self.optimizer_agent_position_preditor.step()

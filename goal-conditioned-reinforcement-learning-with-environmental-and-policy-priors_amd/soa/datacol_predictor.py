@@ -64,6 +64,9 @@ def collect_windows(engine, n_records, rollout_steps=128):
     filled = 0
     T = int(rollout_steps)
     init_frame = None
+    out = engine.alloc_outputs(T)                       # ONE slab for every rollout (native record layout -> the pipelined
+    #                                                     kernel); a slab per iteration would map / unmap hundreds of 2 MiB
+    #                                                     chunks each time and leave its address range reserved
     while filled < n_records:
         engine.reset()
         if init_frame is None:
@@ -72,7 +75,6 @@ def collect_windows(engine, n_records, rollout_steps=128):
             m[15 * 17 + 3] = 0.3
             init_frame = m.to(engine.device)
         acts = engine.fill_actions(T)                   # the engine's Philox stream: uniform over the 5 policy actions
-        out = engine.alloc_outputs(T)                   # native record layout -> the pipelined rollout kernel (one launch)
         engine.rollout(T, out, actions=acts, autoreset=True, policy_idx=True)
         w = windows_from_rollout(out["matrix"], out["pos"], acts, out["reward"], out["terminated"], out["truncated"],
                                  init_frame)

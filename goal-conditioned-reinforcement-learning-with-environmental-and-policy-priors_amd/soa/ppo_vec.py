@@ -19,6 +19,25 @@ INIT_POS = (15.0, 3.0)        # agent (y, x) after reset (twoarmy_v6.py:10, env_
 GOAL_YX = (2.0, 14.0)
 
 
+def agree_on_steps(local_steps, device):
+    """Optimiser steps per epoch every rank will take: the MAX over ranks of ceil(samples / minibatch) (relabelled-record
+    counts differ per rank, and every rank must take part in the same number of gradient all-reduces)."""
+    if not (torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1):
+        return int(local_steps)
+    on_cpu = torch.distributed.get_backend() != "nccl"
+    m = torch.tensor([int(local_steps)], device="cpu" if on_cpu else device)
+    torch.distributed.all_reduce(m, op=torch.distributed.ReduceOp.MAX)
+    return int(m.item())
+
+
+def padded_permutation(perm, n_steps, minibatch):
+    """An epoch's index stream stretched to exactly n_steps minibatches: a rank with fewer samples than its peers
+    revisits samples of this epoch (cyclically) so that it issues as many gradient all-reduces as every other rank."""
+    if n_steps > -(-perm.numel() // minibatch):
+        perm = perm[torch.arange(n_steps * minibatch, device=perm.device) % perm.numel()]
+    return perm
+
+
 class VecPPOTrainer:
     def __init__(self, agent, engine, rollout_steps=128, minibatch=4096, value_chunk=16384, frame_codes=False):
         """frame_codes=True stores the rollout's frames as uint8 codes (TW_F_MATRIX_CODE; 304 B instead of 1168 B
@@ -42,6 +61,7 @@ class VecPPOTrainer:
         self._graph, self._graph_warm = None, False
         self._graph_base = torch.zeros(1, dtype=torch.int64, device=d)
         self.time_phases = False                  # update(): wall time of target computation vs epochs (one extra sync)
+        self.value_rows = 0                       # critic forward rows issued by the last compute_targets (incl. padding)
         self.last_update_timing = None
         if self.frame_codes:
             self.frames_buf = torch.zeros((T + 4, N, 304), dtype=torch.uint8, device=d)
@@ -68,6 +88,7 @@ class VecPPOTrainer:
         self.pos[:4] = self.init_pos
         agent.to(d)
         self.her = None                       # relabelled index records of the current rollout (relabel())
+        self.her_out_of_pattern = 0           # records of the last update whose V(s') could not be taken from a neighbour
         # hindsight relabelling looks back over every rollout an episode ending now may have started in:
         # ceil((max_steps - 1) / T) earlier ones; each entry is (pos, term, trunc, reward, age0) of one rollout
         self.max_steps = int(getattr(engine, "max_steps", 50))
@@ -236,6 +257,7 @@ class VecPPOTrainer:
             if self.fixed_shapes and n_real < C:
                 sl = torch.cat([sl, sl[torch.arange(C - n_real, device=self.device) % n_real]])   # pad: one conv batch size
             x, p = self._policy_x(t_idx[sl], n_idx[sl], after)
+            self.value_rows += int(sl.numel())
             out = self.agent.critic_value(x, p, self.goal_input(goal[sl], after)).view(-1)
             v[i:i + n_real] = out[:n_real]
         return v
@@ -259,10 +281,28 @@ class VecPPOTrainer:
         nv[need] = self._values_one(t_idx[need], n_idx[need], goal[need], True)
         return v, nv
 
+    def _her_next_values(self, h, hgoal, hv):
+        """V(s') of relabelled records from V(s) of the record behind them.  Valid only while the records come as runs
+        of consecutive steps of one env under one goal, each run ending with its done record (ppo_her_relabel's emission
+        order, also after relabel()'s `keep` filter): checked on the device (one sync per update, next to the ones the
+        record count already costs); records that break the pattern -- external `choices`, a changed kernel -- get
+        their own evaluation of the after-state instead of a neighbour's value."""
+        t, n, done = h["t"].long(), h["n"].long(), h["done"] != 0
+        g = h["goal"]
+        ok_next = torch.zeros_like(done)
+        ok_next[:-1] = (n[1:] == n[:-1]) & (t[1:] == t[:-1] + 1) & (g[1:] == g[:-1]).all(-1)
+        need = torch.nonzero(done | ~ok_next).view(-1)          # run ends, plus anything out of pattern (incl. the last row)
+        hnv = torch.full_like(hv, float("nan"))                  # a row nobody fills would poison the loss visibly
+        hnv[:-1] = hv[1:]
+        hnv[need] = self._values_one(h["t"][need], h["n"][need], hgoal[need], True)
+        self.her_out_of_pattern = int((~done & ~ok_next).sum())
+        return hnv
+
     @torch.no_grad()
     def compute_targets(self):
         T, N = self.T, self.N
         total = T * N
+        self.value_rows = 0
         idx = torch.arange(total, device=self.device)
         done = (self.term | self.trunc).contiguous()
         goal = self.sample_goal(idx // N, idx % N, self.goal1.expand(total, 2), done.view(-1))
@@ -281,10 +321,7 @@ class VecPPOTrainer:
                 # done record (ppo_her_relabel's emission order), so V(s'_j) of a record that is not done is V(s) of the
                 # record behind it; only the prefix ends are evaluated on their after-states
                 hv = self._values_one(h["t"], h["n"], hgoal, False)
-                hnv = torch.empty_like(hv)
-                hnv[:-1] = hv[1:]
-                ends = torch.nonzero(h["done"]).view(-1)
-                hnv[ends] = self._values_one(h["t"][ends], h["n"][ends], hgoal[ends], True)
+                hnv = self._her_next_values(h, hgoal, hv)
             else:
                 hv, hnv = self._values(h["t"], h["n"], hgoal)
             H = hv.numel()
@@ -325,16 +362,11 @@ class VecPPOTrainer:
         local_steps = n_steps = -(-total // self.minibatch)
         synced = ag.grad_sync is not None and torch.distributed.is_initialized()
         if synced:
-            # relabelled-record counts differ per rank; every rank must take part in the same number of all-reduces
-            m = torch.tensor([n_steps], device=self.device)
-            torch.distributed.all_reduce(m, op=torch.distributed.ReduceOp.MAX)
-            n_steps = int(m.item())
+            n_steps = agree_on_steps(n_steps, self.device)
         for ep in range(ag.K_epochs):
             perm = (torch.randperm(total) if permutations is None else torch.as_tensor(permutations[ep])).to(self.device)
-            if synced and n_steps > -(-perm.numel() // self.minibatch):
-                # a rank with fewer samples than its peers (relabelled-record counts differ) revisits samples of this
-                # epoch so that it issues exactly n_steps gradient all-reduces like every other rank
-                perm = perm[torch.arange(n_steps * self.minibatch, device=self.device) % perm.numel()]
+            if synced:
+                perm = padded_permutation(perm, n_steps, self.minibatch)
             done_steps = 0
             for i in range(0, perm.numel(), self.minibatch):
                 idx = perm[i:i + self.minibatch]

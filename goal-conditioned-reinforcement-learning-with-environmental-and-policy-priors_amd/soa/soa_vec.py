@@ -152,9 +152,8 @@ class VecSoATrainer(VecPPOTrainer):
         if synced:
             # EVERY rank joins this collective, also one without a single orientation sample (no success, no
             # hindsight record): it then takes part in each gradient all-reduce with zero gradients
-            m = torch.tensor([n_steps], device=self.device)
-            torch.distributed.all_reduce(m, op=torch.distributed.ReduceOp.MAX)
-            n_steps = int(m.item())
+            from .ppo_vec import agree_on_steps
+            n_steps = agree_on_steps(n_steps, self.device)
         if n_steps == 0:
             return None
         ag.agent_position_preditor.train()

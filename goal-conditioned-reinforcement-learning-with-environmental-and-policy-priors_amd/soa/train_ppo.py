@@ -98,7 +98,7 @@ def main(argv=None, predictor=False, soa=False):
                                 ([agent.encoder, agent.decoder, agent.predictor] if (predictor or soa) else []) +
                                 ([agent.agent_position_preditor] if soa else []))
     if world > 1:
-        agent.grad_sync = twdist.GradBucket(list(agent.actor.parameters()) + list(agent.critic.parameters()))
+        agent.grad_sync = twdist.GradBucket([list(agent.actor.parameters()), list(agent.critic.parameters())])
         if soa:                                  # the orientation head has its own optimiser step, hence its own bucket
             agent.grad_sync_orient = twdist.GradBucket(list(agent.agent_position_preditor.parameters()))
 

@@ -148,6 +148,9 @@ int tw_view_size(const tw_engine *e);
 int tw_last_hip_error(void);
 const char *tw_last_error_message(void);
 const char *tw_version(void);
+/* First 16 hex digits of sha256(kernel sources + include/ headers) the library was compiled from (csrc/Makefile).
+ * bench.py only reports a committed HBM-traffic counter profile whose recorded id equals this one. */
+const char *tw_build_id(void);
 
 /* Output buffers of one T-step rollout (or one step: T = 1) allocated by the engine in its native MI355X layout,
  * all carved out of ONE device slab.  This is the counterpart of the arrays the reference's rollout loop appends to

@@ -35,6 +35,29 @@ def test_gpus_2_spawns_two_ranks_and_reports_n_gpus_2():
     assert res["data"] == "rehearsal" and res["value"] == 0.0  # never mistaken for a measurement
 
 
+def test_gpus_8_rehearsal_bucket_protocol_and_slab_backing_gather():
+    """World size 8 over gloo: the launcher, the per-rank slab-backing gather and the two-group gradient-bucket protocol
+    with ranks that ask for different step counts."""
+    p, lines = _run(["--gpus", "8", "--steps", "3", "--warmup", "1", "--rehearse"], timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1, p.stdout
+    res = json.loads(lines[0])
+    cfg = res["config"]
+    assert res["n_gpus"] == 8 and cfg["collective"]["sanity_allreduce_of_ones"] == 8.0
+    assert cfg["slab_backing"] == {"per_rank": ["rehearsal"] * 8, "agree": True}
+    gb = cfg["grad_bucket"]
+    assert gb["optimiser_steps"] == 1 + 3 + 2                     # the max over ranks of (W + K + rank % 3)
+    assert gb["allreduces_issued"] == 2 * gb["optimiser_steps"] and gb["gradients_copied_into_bucket"] == 0
+    assert gb["replicas_identical"] is True
+
+
+def test_ranks_that_disagree_on_the_slab_backing_abort_the_run():
+    p, lines = _run(["--gpus", "4", "--steps", "1", "--warmup", "0", "--rehearse"], env_extra={"TW_REHEARSE_ODD_RANK": "2"},
+                    timeout=600)
+    assert p.returncode != 0 and not lines
+    assert "disagree on the output slab backing" in p.stderr
+
+
 def test_launched_by_torchrun_like_the_driver():
     """The driver's own form: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ..."""
     env = dict(os.environ)

@@ -364,3 +364,51 @@ def test_placement_tuned_outputs_leave_the_env_state_untouched():
     for k in ("obs", "matrix", "pos", "reward", "terminated", "truncated"):
         assert np.array_equal(out[k].cpu().numpy(), ref[k]), k
     eng.close()
+
+
+def test_slab_free_then_realloc_writes_every_row():
+    """Regression for the slab incident ("engine slab"): allocate a slab, roll out into it, drop it (so
+    tw_free_outputs unmaps / releases its chunks), allocate again, prefill the new slab with 0x77 and run the pipelined
+    and the sequential rollout into fresh slabs: equal outputs, equal to the oracle, no row left at the prefill value.
+    Runs ONCE; whatever tw_free_outputs does with the address range (kept reserved today) must keep this green."""
+    import gc
+    N, T = 4096, 128
+    ref = _oracle(6, N, T, 17, 0)
+    eng = _engine(6, N, 17, seed=SEED)
+    acts = eng.fill_actions(T)
+    state0 = eng.get_state()
+    out = eng.alloc_outputs(T)
+    assert out["matrix"]._tw_layout.startswith("2048-byte records")
+    first_ptr = out["matrix"].data_ptr()
+    eng.rollout(T, out, actions=acts)
+    torch.cuda.synchronize()
+    del out
+    gc.collect()                                           # last tensor gone -> _OutputSlab.__del__ -> tw_free_outputs
+    results = {}
+    for pipe in (True, False):
+        eng.set_state(*state0)
+        eng.set_pipeline(pipe)
+        out = eng.alloc_outputs(T)
+        rows = padded_rows(out["matrix"], 2, 292)          # the whole 2048-byte record starts at the matrix row
+        rec = rows.view(torch.uint8).as_strided((T, N, 2048), (N * 2048, 2048, 1))
+        rec.fill_(0x77)
+        for k in ("pos", "reward", "terminated", "truncated"):
+            out[k].view(torch.uint8).fill_(0x77)
+        torch.cuda.synchronize()
+        eng.rollout(T, out, actions=acts)
+        torch.cuda.synchronize()
+        # a row the kernel never reached still reads 0x77 in its first matrix word (a float matrix cell is one of
+        # +-0.9, -0.5, 0.3: never 0x77777777)
+        first_words = rec[..., :4].contiguous().view(torch.int32)
+        assert int((first_words == 0x77777777).sum()) == 0, "pipe=%s: rows never written after a slab re-allocation" % pipe
+        for k in ("obs", "matrix", "pos", "reward", "terminated", "truncated"):
+            assert np.array_equal(out[k].cpu().numpy(), ref[k]), (k, pipe)
+        results[pipe] = {k: out[k].clone() for k in out}
+        ptr = out["matrix"].data_ptr()
+        del out, rows, rec, first_words
+        gc.collect()
+    for k in results[True]:
+        assert torch.equal(results[True][k], results[False][k]), k
+    assert eng.fallback_count() == 0
+    eng.close()
+    assert first_ptr and ptr

@@ -4,7 +4,8 @@
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py \\
       --no-cpu-baseline --steps 8 --warmup 2
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py ... (same)
-  python tools/traffic_from_pmc.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/r01_traffic.json
+  python tools/traffic_from_pmc.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/r03_traffic.json
+(tools/gpu_traffic.sh does all three on the GPU box)
 
 FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE is doubled (gfx950 reports half of a wide coalesced read stream),
 WRITE_SIZE is taken as is (exact for 16-byte-per-lane stores).  The median over the 128-step launches is used.
@@ -14,7 +15,11 @@ import glob
 import json
 import os
 import statistics
+import subprocess
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 KERNEL = "tw_pipe_kernel<6, 16>"
 ALGORITHMIC = (4 + 17 * 17 * 3 + 289 * 4 + 8 + 4 + 1 + 1 + 2 * (289 + 289 + 48 * 4) / 128.0) * 4096 * 128
@@ -30,6 +35,20 @@ def counter_values(directory, counter):
     return sorted(vals)
 
 
+def build_id():
+    """tw_build_id() of the library in the tree (the one the profiled bench.py run loaded)."""
+    from twoarmy_amd import _lib
+    return _lib.lib().tw_build_id().decode()
+
+
+def git_head():
+    try:
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True,
+                                       stderr=subprocess.DEVNULL).strip()
+    except Exception:
+        return None                                     # the GPU box's snapshot carries no .git
+
+
 def main():
     fetch = counter_values(sys.argv[1], "FETCH_SIZE")
     write = counter_values(sys.argv[2], "WRITE_SIZE")
@@ -37,7 +56,7 @@ def main():
     fb = 2.0 * statistics.median(fetch) * 1024.0
     wb = statistics.median(write) * 1024.0
     print(json.dumps({
-        "round": 2, "kernel": KERNEL,
+        "round": 3, "kernel": KERNEL, "build_id": build_id(), "git_head": git_head(),
         "config": "bench.py default: v6, 4096 envs, T=128 steps per launch, view 17, record layout (tw_alloc_outputs)",
         "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and, in a separate pass, --pmc WRITE_SIZE; median over the "
                   "128-step launches; counters are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a "
