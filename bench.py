@@ -381,7 +381,7 @@ def run_engine_mode(args, rank, world, dev, coll):
     run(0, warm_launches - 8)
     # R timed regions of exactly K launches each, every one bracketed by barrier + synchronize on both sides; the line
     # reports the MEDIAN region (value, ms_per_step, roofline.kernel_ms) and the spread of all of them
-    R = args.regions if args.regions > 0 else max(25, int(100.0 / (K * est_ms)) + 1)
+    R = args.regions if args.regions > 0 else max(25, int(110.0 / (K * est_ms)) + 1)
     wall_s, ev_ms_all = [], []
     for r_ in range(R):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
