@@ -1040,6 +1040,24 @@ constexpr int PGRP = TW_PGRP;
 constexpr uint32_t REC_VALID = 0x80000000u;
 
 struct Dyn { int b0, pone, i1, i2, patrol, o1y0, o2x0; };
+// rare events of the logic loop (wall drop, patrol spawn, episode end): their code is laid out behind the loop so that the
+// common path falls through (a taken branch costs the lone logic wave an instruction-buffer refill)
+#ifdef LG_NOEXPECT
+#define LG_RARE(c) (c)
+#else
+#define LG_RARE(c) __builtin_expect(!!(c), 0)
+#endif
+#ifndef LG_UNROLL
+#define LG_UNROLL 1
+#endif
+// (x << K) | acc in ONE instruction; written as plain C the optimiser re-balances a chain of these into separate shifts
+// plus 3-input ORs (17 instead of 7 instructions for the record word)
+template <int K>
+__device__ __forceinline__ uint32_t lshl_or(uint32_t x, uint32_t acc) {
+    uint32_t r;
+    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "n"(K), "v"(acc));
+    return r;
+}
 
 __device__ __forceinline__ uint32_t static_cell(int x, int y) {      // _gen_grid without the balls
     if (x == 0 || y == 0 || x == GS - 1 || y == GS - 1) return C_WALL;
@@ -1171,38 +1189,64 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
     const int mat_laneb_off = (MAT_OFF + 4 * (lane < 9 ? 64 + lane : 72)) * 4;
 
     // ---- LOGIC state of wave 0 (lane e <-> env n0+e): only the fields the closed-form transition touches
-    //      (everything else stays in the LDS copy of the record and is written back unchanged)
+    //      (everything else stays in the LDS copy of the record and is written back unchanged).
+    // The logic wave is ISSUE-bound (a lone wave gets one instruction of any kind per ~4.3 cycles), so the state is kept
+    // in the form that needs the fewest instructions per step -- integers and bit masks, no booleans (every && / || of
+    // two lane predicates is an extra scalar instruction on top of the two compares):
+    //   posw   agent position, x | y << 5 (the record's low 10 bits; as a shift count the hardware only reads x)
+    //   ph2    2 * (step_move % 12): index of the 2-bit tables LG_B0 (ball triple), LG_GL / LG_GH (patrol move gates);
+    //          12 = lcm of the 6-step ball cycle and the 4-step gate of the column patrol
+    //   c1x2   2 * phase of the column patrol on its 4-step bounce (y, up1): (3,0) (4,0) (5,1) (4,1)
+    //   c2x3   3 * phase of the square patrol on its 10-step bounce (x, right2): (5,1) (6,1) .. (9,1) (10,0) (9,0) .. (6,0)
+    //          (the patrols never leave these cycles in play; an injected state off them goes to the sequential kernel)
+    //   pl2 / ph3   2 / 3 when the column / the square may move this episode (patrol & Update_longitudinal / _horizontal)
+    //   npone  ~0 until the wall blocks have dropped, pm ~0 while the patrols exist, w1 / w2 row masks of the dropped wall blocks, dynw the record bits that only
+    //          change at a drop / spawn / episode end (pack_record layout: 17-18 i1-9, 19-20 i2-6, 22 pone, 24 patrol,
+    //          plus the valid bit), seenw the same flags as the observation of the NEXT step sees them (bits 21, 23)
     const bool lg_active = wave == 0 && lane < PG && n0 + lane < N;
+    constexpr uint32_t LG_B0 = 0x019019u;       // (b0 - 6) per phase: 1 2 1 0 0 0 | 1 2 1 0 0 0      (twoarmy_v6.py:96-112)
+    constexpr uint32_t LG_GL = 0x3C30F3u;       // column gate open: step_move % 6 in {0, 3} or % 4 == 2 -> phases 0 2 3 6 9 10
+    constexpr uint32_t LG_GH = 0xFF3FF3u;       // square gate open: step_move % 6 != 1 -> all phases but 1 and 7
+    constexpr uint32_t LG_Y1 = 0x64u;           // column top row - 3 per phase: 0 1 2 1
+    constexpr uint32_t LG_X2 = 0x0A72C688u;     // square left column - 5 per phase: 0 1 2 3 4 5 4 3 2 1 (3 bits each)
+    constexpr uint32_t GOALW = 14u | (2u << 5);
     struct {
-        int ax, ay, step_count, step_move, m6, m4, up1, right2, upd_long, upd_horiz, risk, first_room2, max_steps,
-            episodes, last_reward, last_term, last_trunc;
-        uint32_t t;
+        int step_count, sm_off, risk, max_steps, episodes, last_reward, last_term, last_trunc, i1, i2;
+        uint32_t posw, ph2, c1x2, c2x3, pl2, ph3, pm, npone, first_room2, upd_long, upd_horiz, w1, w2, dynw, seenw, t;
     } s;
-    Dyn d;
+    bool bad = false;
     {
         const int32_t *r = recs + (lane < PG ? lane : 0) * REC;
-        s.ax = r[TW_AX]; s.ay = r[TW_AY]; s.step_count = r[TW_STEP_COUNT]; s.step_move = r[TW_STEP_MOVE];
-        s.m6 = (int)((uint32_t)s.step_move % 6u); s.m4 = s.step_move & 3;
-        s.up1 = r[TW_UP1]; s.right2 = r[TW_RIGHT2]; s.upd_long = r[TW_UPD_LONG]; s.upd_horiz = r[TW_UPD_HORIZ];
-        s.risk = r[TW_RISK]; s.first_room2 = r[TW_FIRST_ROOM2]; s.max_steps = r[TW_MAX_STEPS];
+        s.posw = (uint32_t)r[TW_AX] | ((uint32_t)r[TW_AY] << 5);
+        s.step_count = r[TW_STEP_COUNT]; s.sm_off = r[TW_STEP_MOVE] - s.step_count;
+        s.ph2 = 2u * ((uint32_t)r[TW_STEP_MOVE] % 12u);
+        s.upd_long = r[TW_UPD_LONG] != 0; s.upd_horiz = r[TW_UPD_HORIZ] != 0;
+        s.risk = r[TW_RISK]; s.first_room2 = r[TW_FIRST_ROOM2] != 0; s.max_steps = r[TW_MAX_STEPS];
         s.episodes = r[TW_EPISODES]; s.last_reward = r[TW_LAST_REWARD]; s.last_term = r[TW_LAST_TERM];
         s.last_trunc = r[TW_LAST_TRUNC]; s.t = (uint32_t)r[TW_T];
-        d.b0 = r[TW_OBX]; d.pone = r[TW_PONE]; d.i1 = r[TW_WALL_I1]; d.i2 = r[TW_WALL_I2]; d.patrol = r[TW_PATROL];
-        d.o1y0 = r[TW_O1Y]; d.o2x0 = r[TW_O2X];
+        const bool pone = r[TW_PONE] != 0;
+        s.npone = pone ? 0u : ~0u; s.i1 = r[TW_WALL_I1]; s.i2 = r[TW_WALL_I2];
+        const bool patrol = r[TW_PATROL] != 0;
+        const int up1 = r[TW_UP1] != 0, right2 = r[TW_RIGHT2] != 0, y1 = r[TW_O1Y], x2 = r[TW_O2X];
+        s.w1 = pone ? 0x30u : 0u; s.w2 = pone ? 3u << s.i2 : 0u;
+        s.dynw = pone ? (((uint32_t)(s.i1 - 9) & 3u) << 17) | (((uint32_t)(s.i2 - 6) & 3u) << 19) | (1u << 22) : 0u;
+        if (patrol) s.dynw |= 1u << 24;
+        s.seenw = (s.dynw & ((1u << 22) | (1u << 24))) >> 1;     // record bits 21 / 23: what gen_obs() sees of pone / patrol
+        s.dynw |= REC_VALID;                                     // the valid bit rides along
+        if (V4 && s.upd_long) s.upd_horiz = 0;    // twoarmy_v4.py:116,148: the first step leaves exactly one of them set
+        // patrol phases; without patrols only the coins up1 / right2 are state (phases 0 / 2 and 5 / 0 carry them)
+        uint32_t c1 = up1 ? 2u : 0u, c2 = right2 ? 0u : 5u;
+        if (V4 && patrol) {
+            c1 = up1 ? (y1 == 4 ? 3u : 2u) : (y1 == 4 ? 1u : 0u);
+            c2 = right2 ? (uint32_t)(x2 - 5) : (uint32_t)(15 - x2);
+            bad |= ((unsigned)(y1 - 3) > 2u) | ((unsigned)(x2 - 5) > 5u) | (up1 ? y1 == 3 : y1 == 5) | (right2 ? x2 == 10 : x2 == 5);
+            c1 &= 3u; c2 = c2 > 9u ? 0u : c2;
+        }
+        s.c1x2 = 2u * c1; s.c2x3 = 3u * c2;
+        s.pm = (V4 && patrol) ? ~0u : 0u;
+        s.pl2 = (V4 && patrol && s.upd_long) ? 2u : 0u; s.ph3 = (V4 && patrol && s.upd_horiz) ? 3u : 0u;
     }
     const bool policy_idx = (p.flags & TW_F_POLICY_IDX) != 0;
-    bool bad = false;
-    // row masks of the two dropped wall blocks and the record bits that only change at a drop / spawn / episode end
-    // (pack_record layout: 17-18 i1-9, 19-20 i2-6, 22 pone, 24 patrol)
-    uint32_t w1 = d.pone ? 0x30u : 0u, w2 = d.pone ? 3u << d.i2 : 0u;
-    uint32_t dynw = d.pone ? (((uint32_t)(d.i1 - 9) & 3u) << 17) | (((uint32_t)(d.i2 - 6) & 3u) << 19) | (1u << 22) : 0u;
-    if (d.patrol) dynw |= 1u << 24;
-    // v4 patrol state machines (see the logic loop); a patrol outside its range cannot be encoded: sequential kernel
-    if (V4) {
-        bad |= d.patrol && (((unsigned)(d.o1y0 - 3) > 2u) | ((unsigned)(d.o2x0 - 5) > 5u));
-        if (s.upd_long) s.upd_horiz = 0;              // twoarmy_v4.py:116,148: the first step leaves exactly one of them set
-    }
-    int s1 = (min(max(d.o1y0, 3), 5) - 3) * 2 + (s.up1 != 0), s2 = (min(max(d.o2x0, 5), 10) - 5) * 2 + (s.right2 != 0);
 
     for (int c0 = 0; c0 < p.T; c0 += PCH) {
         const int len = min(PCH, p.T - c0);
@@ -1214,27 +1258,28 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
             ring[i] = (n0 + e < N) ? 0u : REC_VALID;        // padding envs of a ragged last block are "done" from the start
             // The draw counter of an env advances by one per step whatever happens, so every Philox word of
             // the chunk is known up front: all 16 waves compute them in parallel and the serial logic wave
-            // only reads one packed word per step (bit0 gate==6, 1-2 wall1, 3-4 wall2, 5-6 spawn, 7 coin A, 8 coin B).
+            // only reads one packed word per step (bits 0-1 gate==6 (both), 2-3 wall1, 4-5 wall2, 6-7 spawn, 8 coin A, 9 coin B).
             const uint32_t eid = p.env_id0 + (uint32_t)(n0 + e);
             const uint32_t tnow = (uint32_t)recs[e * REC + TW_T] + (uint32_t)(c0 + tl);
             uint32_t w[4], packed = 0;
             if (V4) {
                 draw_block(p.seed_lo, p.seed_hi, eid, tnow, 0, w);
-                packed = ((w[TW_S_GATE] % 10u) == 6u ? 1u : 0u) | ((w[TW_S_WALL1] & 3u) << 1) | ((w[TW_S_WALL2] & 3u) << 3) |
-                         ((w[TW_S_SPAWN] & 3u) << 5);
+                packed = ((w[TW_S_GATE] % 10u) == 6u ? 3u : 0u) | ((w[TW_S_WALL1] & 3u) << 2) | ((w[TW_S_WALL2] & 3u) << 4) |
+                         ((w[TW_S_SPAWN] & 3u) << 6);
             }
             draw_block(p.seed_lo, p.seed_hi, eid, tnow, 1, w);
-            packed |= ((w[0] & 1u) << 7) | ((w[1] & 1u) << 8);
+            packed |= ((w[0] & 1u) << 8) | ((w[1] & 1u) << 9);
             // The action is decoded here as well (Env_transact.env_action 4 -> done, twoarmy_v6.py:85-86 ">= 7 -> left",
-            // minigrid.py:1347-1394 move table): bits 16-17 dx + 1, 18-19 dy + 1, bit 20 "the reference raises"
-            // (negative action, env actions 4 / 5: AttributeError) -- the serial chain only adds and tests.
+            // minigrid.py:1347-1394 move table): the upper half of the word is the signed step of the packed position
+            // (dx + 32 dy), bit 10 "the reference raises" (negative action, env actions 4 / 5: AttributeError) -- the
+            // serial chain only adds and tests.
             int a = act_in;
             const bool neg = a < 0;
             if (policy_idx && a == 4) a = 6;
             if (a >= 7) a = 0;
             const bool raises = neg || ((0x4Fu >> (a & 7)) & 1u) == 0u;
-            const uint32_t dx1 = raises ? 1u : (0x1558u >> (2 * a)) & 3u, dy1 = raises ? 1u : (0x1585u >> (2 * a)) & 3u;
-            drw[i] = packed | (dx1 << 16) | (dy1 << 18) | ((raises ? 1u : 0u) << 20);
+            const int dx = raises ? 0 : (int)((0x1558u >> (2 * a)) & 3u) - 1, dy = raises ? 0 : (int)((0x1585u >> (2 * a)) & 3u) - 1;
+            drw[i] = packed | ((raises ? 1u : 0u) << 10) | ((uint32_t)(dx + 32 * dy) << 16);
         }
         __syncthreads();
 #ifdef TW_STAMP
@@ -1251,123 +1296,118 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
             const uint32_t *drp = drw + (lane < PG ? lane : 0);
             uint32_t *rgp = ring + (lane < PG ? lane : 0);
             uint32_t dr_next = *drp, badw = 0u, last_rec = 0u;
+            // the record of step t is published at the top of step t + 1 (the LDS write's latency then overlaps that step; a
+            // write at the bottom was followed, a few instructions later, by the wait for the next step word, which had to
+            // wait for the write as well: LDS operations of a wave retire in order).  Step 0's slot still holds 0: a harmless first write.
+            uint32_t pend = 0u, *pendp = rgp;
             // the whole loop sits inside the lane predicate: one exec set-up per chunk instead of an if / else per step
-            if (lg_active) for (int tl = 0; tl < len; ++tl) {
-                {
-                    const uint32_t dr = dr_next;
-                    drp += PG;
-                    dr_next = *drp;                                       // next step's word: its LDS latency leaves the chain
-                    badw |= dr;                                           // bit 20: the reference raises on this action
-                    s.step_move += 1;
-                    s.m6 = s.m6 == 5 ? 0 : s.m6 + 1;
-                    if (V4) s.m4 = (s.m4 + 1) & 3;
-                    const int m6 = s.m6;
-                    // row-8 balls (twoarmy_v6.py:96-112): the triple's x is a pure function of step_move % 6
-                    // (7 at reset, +1 for m6 in {0,1}, -1 for {2,3}, 0 for {4,5}); verified against the record at launch
-                    const int b0 = (int)((0x666787u >> (4 * m6)) & 15u);
-                    if (V4) {                                             // twoarmy_v4.py:115-176
-                        // column patrol (y, up1) and square patrol (x, right2) as two small state machines:
-                        // s1 = (y - 3) * 2 + up1, s2 = (x - 5) * 2 + right2, one table lookup per move.  The gates are
-                        // bit tables over step_move % 6: the column moves when m6 in {0, 3} (or m4 == 2, or the drawn
-                        // gate), the square when m6 != 1 (or the gate).  States that would leave the range -- (3, up),
-                        // (5, down), (10, right), (5, left); never reached in play -- map to themselves and raise `bad`,
-                        // which is what the literal move + range check + clamp does.
-                        const uint32_t gate = dr & 1u;
-                        const uint32_t gl = (((0x09u >> m6) | gate) & 1u) | (uint32_t)(s.m4 == 2);
-                        const uint32_t gh = ((0x3Du >> m6) | gate) & 1u;
-                        const bool mv1 = (gl & (uint32_t)s.upd_long & (uint32_t)d.patrol) != 0u;
-                        const bool mv2 = (gh & (uint32_t)s.upd_horiz & (uint32_t)d.patrol) != 0u;
-                        bad |= (mv1 & ((s1 == 1) | (s1 == 4))) | (mv2 & ((s2 == 0) | (s2 == 11)));
-                        const int n1 = (int)((0x1C14Au >> (3 * s1)) & 7u);                    // 0>2 1>1 2>5 3>0 4>4 5>3
-                        const int n2 = (int)(((s2 < 8 ? 0x94725130u : 0xB8A6u) >> (4 * (s2 & 7))) & 15u);
-                        s1 = mv1 ? n1 : s1;                               // 0>0 1>3 2>1 3>5 4>2 5>7 6>4 7>9 | 8>6 9>10 10>8 11>11
-                        s2 = mv2 ? n2 : s2;
-                    }
-                    const int py1 = 3 + (s1 >> 1), px2 = 5 + (s2 >> 1);   // patrol column top row / square left column
-                    // MiniGridEnv.step (minigrid.py:1333-1441): is the target cell free?  One bitmask per grid row
-                    // (bit x set = cell (x, ty) blocks): border / row-8 walls + ball triple + dropped 2x2 wall blocks
-                    // (+ patrol column and square).  The goal cell (14, 2) is never blocked.
-                    s.step_count += 1;
-                    const int tx = s.ax + (int)((dr >> 16) & 3u) - 1;
-                    const int ty = s.ay + (int)((dr >> 18) & 3u) - 1;
-                    uint32_t rb = ty == 8 ? (0x1F83Fu | (7u << b0)) : 0x10001u;
-                    rb = (unsigned)(ty - 1) > 14u ? 0x1FFFFu : rb;
-                    rb |= (unsigned)(ty - d.i1) <= 1u ? w1 : 0u;
-                    rb |= (unsigned)(ty - 11) <= 1u ? w2 : 0u;
-                    if (V4) {
-                        const uint32_t pm = d.patrol ? ~0u : 0u;
-                        rb |= (unsigned)(ty - py1) <= 2u ? ((1u << 12) & pm) : 0u;
-                        rb |= (unsigned)(ty - 4) <= 1u ? ((3u << px2) & pm) : 0u;
-                    }
-                    const bool enter = ((rb >> tx) & 1u) == 0u;
-                    s.ax = enter ? tx : s.ax;
-                    s.ay = enter ? ty : s.ay;
-                    int terminated = (tx == 14) & (ty == 2);
-                    int truncated = s.step_count >= s.max_steps;
-                    const uint32_t seen = dynw & ((1u << 22) | (1u << 24));   // what gen_obs() saw: pone / patrol before this step's drop / spawn
-                    // ---- after gen_obs(): wall drop, patrol spawn (twoarmy_v6.py:182-198, v4:181-225)
-                    if (!d.pone && (s.ax > 3 || s.ay < 14)) {
-                        d.i1 = V4 ? 9 + (int)((dr >> 1) & 3u) : 11;
-                        d.i2 = V4 ? 6 + (int)((dr >> 3) & 3u) : 8;
-                        d.pone = 1;
-                        w1 = 0x30u; w2 = 3u << d.i2;
-                        dynw = (dynw & ~(15u << 17)) | ((uint32_t)(d.i1 - 9) << 17) | ((uint32_t)(d.i2 - 6) << 19) | (1u << 22);
-                    }
-                    if (V4 && !d.patrol && s.ay <= 8) {                    // column at rows 4..6, square at x = 6 + draw
-                        s2 = (int)((1u + ((dr >> 5) & 3u)) << 1) | (s2 & 1);
-                        s1 = 2 | (s1 & 1);
-                        d.patrol = 1;
-                        dynw |= 1u << 24;
-                    }
-                    // shaped reward (twoarmy_v6.py:231-294)
-                    int reward = R_STEP;
-                    const bool in_span = (unsigned)(s.ax - b0) <= 2u;
-                    bool hit = in_span & (s.ay == 8);
-                    reward = hit ? R_HIT : reward;
-                    reward = (in_span & (s.ay == 9)) ? R_RISK : reward;
-                    if (V4) {                                              // twoarmy_v4.py:242-280, as column bitmasks of row ay
-                        const int y1 = 3 + (s1 >> 1), x2 = 5 + (s2 >> 1);  // after this step's spawn
-                        const uint32_t pm = d.patrol ? ~0u : 0u;
-                        const uint32_t colr = (unsigned)(s.ay - y1) <= 2u ? pm : 0u, sqr = (unsigned)(s.ay - 4) <= 1u ? pm : 0u;
-                        const uint32_t hitm = (colr & (1u << 12)) | (sqr & (3u << x2));
-                        const uint32_t riskm = (colr & (1u << 11)) | (sqr & (9u << (x2 - 1))) | ((s.ay == 6 ? pm : 0u) & (3u << x2));
-                        const bool phit = ((hitm >> s.ax) & 1u) != 0u, prisk = ((riskm >> s.ax) & 1u) != 0u;
-                        reward = prisk ? R_RISK : reward;
-                        reward = phit ? R_HIT : reward;
-                        hit |= phit;
-                    }
-                    truncated |= hit;
-                    const bool room2 = s.first_room2 & (s.ay == 7);
-                    reward = room2 ? R_ROOM2 : reward;
-                    s.first_room2 = room2 ? 0 : s.first_room2;
-                    s.risk += (reward == R_RISK);
-                    truncated |= (reward == R_RISK) & (s.risk > 5);
-                    if (terminated) reward = R_GOAL;
-                    // record of this env-step (pack_record's layout): assembled from the registers that already hold
-                    // their fields in place; single-word publish, the logic wave issues NO vector-memory op in its loop
-                    uint32_t rec = (uint32_t)s.ax | ((uint32_t)s.ay << 5) | ((uint32_t)(b0 - 6) << 10) | dynw | (seen >> 1) |
-                                   ((uint32_t)reward << 25) | ((uint32_t)terminated << 28) | ((uint32_t)(truncated != 0) << 29) |
-                                   REC_VALID;
-                    if (V4) rec |= ((uint32_t)(s1 >> 1) << 12) | ((uint32_t)(s2 >> 1) << 14);
-                    if (terminated || truncated) {                        // twoarmy_v6.py:296-318 + auto-reset
-                        s.step_move = 0; s.m6 = 0; s.m4 = 0; s.first_room2 = 1; s.risk = 0;
-                        const int ca = (dr >> 7) & 1, cb = (dr >> 8) & 1;
-                        s1 = 1 - ca; s2 = ca;                             // up1 = 1 - ca, right2 = ca; no patrol until the next spawn
-                        s.upd_horiz = 1 - cb; s.upd_long = cb;
-                        s.episodes += 1;
-                        d.pone = 0; d.patrol = 0; w1 = 0u; w2 = 0u; dynw = 0u;
-                        s.ax = 3; s.ay = 15; s.step_count = 0;
-                    }
-                    last_rec = rec;
-                    *rgp = rec;
-                    rgp += PG;
+            if (lg_active)
+#pragma unroll LG_UNROLL
+            for (int tl = 0; tl < len; ++tl) {
+                const uint32_t dr = dr_next;
+                drp += PG;
+                dr_next = *drp;                                           // next step's word: its LDS latency leaves the chain
+                badw |= dr;                                               // bit 10: the reference raises on this action
+                // step_move += 1 (twoarmy_v6.py:88); row-8 balls (:96-112): the triple's x is a pure function of
+                // step_move % 6 (7 at reset, +1 for {0,1}, -1 for {2,3}, 0 for {4,5}); verified against the record at launch
+                s.ph2 = s.ph2 == 22u ? 0u : s.ph2 + 2u;
+                const uint32_t b0o = (LG_B0 >> s.ph2) & 3u;
+                const uint32_t balls = 0x1C0u << b0o;                     // 7 << b0
+                if (V4) {                                                 // twoarmy_v4.py:115-176
+                    // the column moves when step_move % 6 in {0, 3} (or % 4 == 2, or the drawn gate), the square when
+                    // step_move % 6 != 1 (or the gate) -- two bit tables over the phase, OR-ed with the gate draw (bits 0-1
+                    // of the step word), AND-ed with "this patrol may move": the phase increment itself
+                    s.c1x2 = (s.c1x2 + (((LG_GL >> s.ph2) | dr) & s.pl2)) & 6u;
+                    s.c2x3 += ((LG_GH >> s.ph2) | dr) & s.ph3;
+                    s.c2x3 = s.c2x3 == 30u ? 0u : s.c2x3;
                 }
+                uint32_t y1o = (LG_Y1 >> s.c1x2) & 3u, x2o = (LG_X2 >> s.c2x3) & 7u;   // column top row - 3, square left column - 5
+                // MiniGridEnv.step (minigrid.py:1333-1441): is the target cell free?  One bitmask per grid row (bit x set
+                // = cell (x, ty) blocks): border / row-8 walls + ball triple + dropped 2x2 wall blocks (+ patrol column and
+                // square).  The goal cell (14, 2) is never blocked.
+                s.step_count += 1;
+                const uint32_t tposw = s.posw + (uint32_t)((int32_t)dr >> 16);
+                *pendp = pend;                                            // previous step's record (see above)
+                const int ty = (int)(tposw >> 5);
+                uint32_t rb = ty == 8 ? (0x1F83Fu | balls) : 0x10001u;
+                rb = (unsigned)(ty - 1) > 14u ? 0x1FFFFu : rb;
+                rb |= (unsigned)(ty - s.i1) <= 1u ? s.w1 : 0u;
+                rb |= (unsigned)(ty - 11) <= 1u ? s.w2 : 0u;
+                if (V4) {
+                    rb |= (unsigned)(ty - 3 - (int)y1o) <= 2u ? (s.pm & 0x1000u) : 0u;
+                    rb |= (unsigned)(ty - 4) <= 1u ? (s.pm & (0x60u << x2o)) : 0u;
+                }
+                s.posw = __builtin_amdgcn_ubfe(rb, tposw, 1u) ? s.posw : tposw;    // bit tx of the row mask (the hardware reads 5 bits of the offset)
+                const uint32_t terminated = tposw == GOALW;
+                uint32_t truncated = s.step_count >= s.max_steps;
+                const uint32_t seen = s.seenw;                            // what gen_obs() saw: pone / patrol before this step's drop / spawn
+                const int ay = (int)(s.posw >> 5);
+                // ---- after gen_obs(): wall drop, patrol spawn (twoarmy_v6.py:182-198, v4:181-225); one test for both:
+                // "still armed" = the sign bit of ~pone-mask, or patrols absent (v4) and ay <= 8
+                const uint32_t armed = V4 ? (s.npone | ((s.posw - (9u << 5)) & ~s.pm)) : s.npone;
+                if (LG_RARE((int32_t)armed < 0)) {
+                    if (s.npone && ((s.posw & 31u) > 3u || ay < 14)) {
+                        s.i1 = V4 ? 9 + (int)((dr >> 2) & 3u) : 11;
+                        s.i2 = V4 ? 6 + (int)((dr >> 4) & 3u) : 8;
+                        s.npone = 0u;
+                        s.w1 = 0x30u; s.w2 = 3u << s.i2;
+                        s.dynw = (s.dynw & ~(15u << 17)) | ((uint32_t)(s.i1 - 9) << 17) | ((uint32_t)(s.i2 - 6) << 19) | (1u << 22);
+                        s.seenw |= 1u << 21;
+                    }
+                    if (V4 && s.pm == 0u && ay <= 8) {                    // column at rows 4..6 keeping up1, square at x = 6 + draw keeping right2
+                        const uint32_t dq = (dr >> 6) & 3u;
+                        s.c1x2 = 2u + (s.c1x2 & 4u);
+                        s.c2x3 = s.c2x3 < 15u ? 3u + 3u * dq : 27u - 3u * dq;
+                        y1o = 1u; x2o = 1u + dq;
+                        s.pm = ~0u; s.pl2 = s.upd_long ? 2u : 0u; s.ph3 = s.upd_horiz ? 3u : 0u;
+                        s.dynw |= 1u << 24;
+                        s.seenw |= 1u << 23;
+                    }
+                }
+                // shaped reward (twoarmy_v6.py:231-294) from two masks of the agent's row: bit x set = standing on x is a
+                // collision (a row-8 ball; v4: a patrol ball, twoarmy_v4.py:242-280) / is "at risk" (under a row-8 ball;
+                // v4: left of the column, left / right of or under the square).  A collision outranks a risk.
+                uint32_t hitm = ay == 8 ? balls : 0u, riskm = ay == 9 ? balls : 0u;
+                if (V4) {
+                    const uint32_t colr = (unsigned)(ay - 3 - (int)y1o) <= 2u ? s.pm : 0u, sqr = (unsigned)(ay - 4) <= 1u ? s.pm : 0u;
+                    const uint32_t sq = 0x60u << x2o;
+                    hitm |= (colr & 0x1000u) | (sqr & sq);
+                    riskm |= (colr & 0x800u) | (sqr & ((sq << 1) | (sq >> 1))) | (ay == 6 ? s.pm & sq : 0u);
+                }
+                const uint32_t hit = __builtin_amdgcn_ubfe(hitm, s.posw, 1u), risky = __builtin_amdgcn_ubfe(riskm, s.posw, 1u);
+                uint32_t reward = hit ? (uint32_t)R_HIT : risky;          // R_RISK == 1, R_STEP == 0
+                truncated |= hit;
+                const uint32_t room2 = ay == 7 ? s.first_room2 : 0u;
+                reward = room2 ? (uint32_t)R_ROOM2 : reward;
+                s.first_room2 &= ~room2;
+                const uint32_t isrisk = reward == (uint32_t)R_RISK;
+                s.risk += (int)isrisk;
+                truncated |= isrisk & (uint32_t)(s.risk > 5);
+                // record of this env-step (pack_record's layout): a chain of shift-ORs onto the registers that already hold
+                // their fields in place (reward | terminated | truncated are bits 25-29: one 5-bit field); single-word
+                // publish, the logic wave issues NO vector-memory op in its loop
+                const uint32_t rtt = lshl_or<4>(truncated, terminated ? ((uint32_t)R_GOAL | 8u) : reward);
+                uint32_t rec = lshl_or<10>(b0o, s.posw | s.dynw | seen);
+                if (V4) rec = lshl_or<14>(x2o, lshl_or<12>(y1o, rec));
+                rec = lshl_or<25>(rtt, rec);
+                if (LG_RARE((terminated | truncated) != 0u)) {            // twoarmy_v6.py:296-318 + auto-reset
+                    const uint32_t ca = (dr >> 8) & 1u, cb = (dr >> 9) & 1u;
+                    s.ph2 = 0u; s.sm_off = 0; s.first_room2 = 1u; s.risk = 0;
+                    s.c1x2 = 4u - 4u * ca; s.c2x3 = 15u - 15u * ca;      // up1 = 1 - ca, right2 = ca; no patrol until the next spawn
+                    s.upd_horiz = 1u - cb; s.upd_long = cb;
+                    s.episodes += 1;
+                    s.npone = ~0u; s.pm = 0u; s.pl2 = 0u; s.ph3 = 0u; s.w1 = 0u; s.w2 = 0u; s.dynw = REC_VALID; s.seenw = 0u;
+                    s.posw = 3u | (15u << 5); s.step_count = 0;
+                }
+                pend = rec; pendp = rgp;
+                rgp += PG;
             }
+            if (lg_active) { *pendp = pend; last_rec = pend; }
             if (lg_active) {                                              // what the loop left for the end of the chunk
                 s.t += (uint32_t)len;                                     // one draw-counter tick per step, whatever happens
                 s.last_reward = (int)((last_rec >> 25) & 7u); s.last_term = (int)((last_rec >> 28) & 1u);
                 s.last_trunc = (int)((last_rec >> 29) & 1u);
-                bad |= ((badw >> 20) & 1u) != 0u;
+                bad |= ((badw >> 10) & 1u) != 0u;
             }
             if (__ballot(bad) != 0ull && lane == 0) atomicOr(p.abnormal, 1);
             __builtin_amdgcn_s_setprio(0);
@@ -1511,24 +1551,26 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
     // ---- write the final state (records from the logic lanes, planes from the closed form)
     if (wave == 0 && lane < PG) {
         int32_t *r = recs + lane * REC;
-        s.up1 = s1 & 1; s.right2 = s2 & 1;                   // the episode-end coins live in the low bits of s1 / s2 (v6 too)
-        if (V4) { d.o1y0 = 3 + (s1 >> 1); d.o2x0 = 5 + (s2 >> 1); }
-        r[TW_AX] = s.ax; r[TW_AY] = s.ay; r[TW_STEP_COUNT] = s.step_count; r[TW_STEP_MOVE] = s.step_move;
-        r[TW_UP1] = s.up1; r[TW_RIGHT2] = s.right2; r[TW_UPD_LONG] = s.upd_long; r[TW_UPD_HORIZ] = s.upd_horiz;
-        r[TW_RISK] = s.risk; r[TW_FIRST_ROOM2] = s.first_room2; r[TW_EPISODES] = s.episodes;
+        const int c1 = (int)(s.c1x2 >> 1), c2 = (int)(s.c2x3 / 3u);
+        const int up1 = c1 >> 1, right2 = c2 < 5;           // the episode-end coins live in the patrol phases (v6 too)
+        const int patrol = s.pm != 0u, o1y0 = 3 + (int)((LG_Y1 >> s.c1x2) & 3u), o2x0 = 5 + (int)((LG_X2 >> s.c2x3) & 7u);
+        r[TW_AX] = (int)(s.posw & 31u); r[TW_AY] = (int)(s.posw >> 5); r[TW_STEP_COUNT] = s.step_count;
+        r[TW_STEP_MOVE] = s.step_count + s.sm_off;
+        r[TW_UP1] = up1; r[TW_RIGHT2] = right2; r[TW_UPD_LONG] = (int)s.upd_long; r[TW_UPD_HORIZ] = (int)s.upd_horiz;
+        r[TW_RISK] = s.risk; r[TW_FIRST_ROOM2] = (int)s.first_room2; r[TW_EPISODES] = s.episodes;
         r[TW_LAST_REWARD] = s.last_reward; r[TW_LAST_TERM] = s.last_term; r[TW_LAST_TRUNC] = s.last_trunc;
         r[TW_T] = (int32_t)s.t; r[TW_ERROR] = 0;
-        r[TW_PONE] = d.pone; r[TW_PATROL] = d.patrol; r[TW_WALL_I1] = d.i1; r[TW_WALL_I2] = d.i2;
-        const int b0_end = (int)((0x666787u >> (4 * s.m6)) & 15u);          // ball triple as a function of step_move % 6
+        r[TW_PONE] = s.npone == 0u; r[TW_PATROL] = patrol; r[TW_WALL_I1] = s.i1; r[TW_WALL_I2] = s.i2;
+        const int b0_end = 6 + (int)((LG_B0 >> s.ph2) & 3u);               // ball triple as a function of step_move % 6
 #pragma unroll
         for (int k = 0; k < 3; ++k) { r[TW_OBX + k] = b0_end + k; r[TW_OBY + k] = 8; }
         if (V4) {
-            r[TW_O1_VALID] = d.patrol; r[TW_O2_VALID] = d.patrol;
-            if (d.patrol) {
+            r[TW_O1_VALID] = patrol; r[TW_O2_VALID] = patrol;
+            if (patrol) {
 #pragma unroll
-                for (int k = 0; k < 3; ++k) { r[TW_O1X + k] = 12; r[TW_O1Y + k] = d.o1y0 + k; }
+                for (int k = 0; k < 3; ++k) { r[TW_O1X + k] = 12; r[TW_O1Y + k] = o1y0 + k; }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { r[TW_O2X + k] = d.o2x0 + (k & 1); r[TW_O2Y + k] = 4 + (k >> 1); }
+                for (int k = 0; k < 4; ++k) { r[TW_O2X + k] = o2x0 + (k & 1); r[TW_O2Y + k] = 4 + (k >> 1); }
             }
         }
     }

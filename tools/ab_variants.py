@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B timing of diagnostic library builds in ONE process on ONE box (box-to-box variance is ~25 %):
-python tools/ab_variants.py std xcd nt ...   (suffixes of libtwoarmy_hip_<suffix>.so, "std" = the shipped library).
+python tools/ab_variants.py std xcd nt ...   (suffixes of libtwoarmy_hip_<suffix>.so, "std" = the shipped library;
+AB_ENVS / AB_VARIANT select the batch size and the env variant, default 4096 / 6).
 Each variant is loaded as its own ctypes handle; rounds are interleaved; all variants write into the SAME output
 buffers (their HBM placement alone moves the time by up to 25 %) unless AB_SHARED_OUTPUTS=0."""
 import ctypes as C
@@ -12,7 +13,8 @@ import torch  # noqa
 import twoarmy_amd  # noqa
 from twoarmy_amd import _lib, engine as eng_mod  # noqa
 
-T, N = 128, 4096
+T, N = 128, int(os.environ.get("AB_ENVS", "4096"))
+VARIANT = int(os.environ.get("AB_VARIANT", "6"))
 names = sys.argv[1:] or ["std"]
 engines = []
 base = _lib.LIB_PATH
@@ -20,7 +22,7 @@ for nm in names:
     _lib._lib = None
     _lib.LIB_PATH = base if nm == "std" else os.path.join(os.path.dirname(base), "libtwoarmy_hip_%s.so" % nm)
     lib = _lib.lib()                                    # binds signatures on this handle
-    e = eng_mod.TwoarmyEngine(6, N, 17, seed=9981)
+    e = eng_mod.TwoarmyEngine(VARIANT, N, 17, seed=9981)
     shared = engines[0][4] if engines and os.environ.get("AB_SHARED_OUTPUTS", "1") == "1" else None
     engines.append((nm, lib, e, e.fill_actions(T), shared if shared is not None else e.alloc_outputs(T)))
     o = engines[-1][4]

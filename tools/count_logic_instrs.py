@@ -23,7 +23,13 @@ def main():
         i1 = next(i for i, l in enumerate(body) if "s_setprio 0" in l)
         ins = [l.split()[0] for l in body[i0:i1] if l.startswith("\t") and not l.strip().startswith((".", ";"))]
         kinds = collections.Counter("salu" if i.startswith("s_") else "lds" if i.startswith("ds_") else "valu" for i in ins)
-        print("v%s PG=%-2s  %3d instructions between the s_setprio pair  %s" % (m.group(2), m.group(3), len(ins), dict(kinds)))
+        # the loop's common path: from its header label to the back-edge (rare-event blocks are laid out behind it)
+        seg = [l for l in body[i0:i1] if l.strip() and not l.strip().startswith((";", ".loc", ".cfi"))]
+        lab = [i for i, l in enumerate(seg) if l.startswith(".LBB")]
+        back = [i for i, l in enumerate(seg) if l.strip().startswith("s_branch")]
+        hot = len([l for l in seg[lab[0]:back[0] + 1] if not l.startswith(".LBB")]) if lab and back else -1
+        print("v%s PG=%-2s  %3d instructions between the s_setprio pair %s, %3d on the loop's common path"
+              % (m.group(2), m.group(3), len(ins), dict(kinds), hot))
         if "--dump" in sys.argv and m.group(2) == "4" and m.group(3) == "4":
             open("/tmp/v4pg4_logic.s", "w").write("\n".join(body[i0:i1]))
 

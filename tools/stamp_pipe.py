@@ -12,7 +12,8 @@ from twoarmy_amd import _lib
 _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libtwoarmy_hip_stamp.so")
 from twoarmy_amd.engine import TwoarmyEngine  # noqa
 variant = int(sys.argv[1]) if len(sys.argv) > 1 else 6
-eng = TwoarmyEngine(variant, 4096, 17, seed=9981)
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+eng = TwoarmyEngine(variant, N, 17, seed=9981)
 T = 128
 acts = eng.fill_actions(T)
 out = eng.alloc_outputs(T)
@@ -24,8 +25,8 @@ lib = _lib.lib()
 lib.tw_debug_stamps.argtypes = [C.c_void_p]
 assert lib.tw_debug_stamps(buf) == 0
 a = np.array(buf[:], dtype=np.float64).reshape(64, 8)
-print("v%d: logic wave %.0f cycles/step; emit wave 1: %d tasks, poll %.0f cycles/task, work %.0f cycles/task" %
-      (variant, a[:, 0].mean() / T, a[:, 3].mean(), a[:, 1].mean() / a[:, 3].mean(), a[:, 2].mean() / a[:, 3].mean()))
+print("v%d, %d envs: logic wave %.1f s_memtime ticks/step (%.0f per 128-step chunk); emit wave 1: %d tasks, poll %.0f cycles/task, work %.0f cycles/task" %
+      (variant, N, a[:, 0].mean() / T, a[:, 0].mean(), a[:, 3].mean(), a[:, 1].mean() / a[:, 3].mean(), a[:, 2].mean() / a[:, 3].mean()))
 buf2 = (C.c_ulonglong * 3072)()
 lib.tw_debug_stamps2.argtypes = [C.c_void_p]
 assert lib.tw_debug_stamps2(buf2) == 0
