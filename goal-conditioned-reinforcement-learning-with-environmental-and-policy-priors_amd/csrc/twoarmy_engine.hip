@@ -107,6 +107,7 @@ struct Params {
     int mat_pitch;            // floats between consecutive envs' matrices
     int flags;
     int record;               // record layout: one 2048-byte block per env-step = 1168 B matrix row | 880 B image row
+    const uint32_t *pipe_tab; // per-engine constant tables of the pipelined kernel (tw_pipe_tables_kernel)
 };
 
 // ---------------------------------------------------------------- Philox4x32-10
@@ -446,6 +447,7 @@ __device__ __forceinline__ void regen_env(uint32_t *env, int lane) {
 #ifdef TW_STAMP
 // Diagnostic build only (make stamp): phase cycle shares via s_memtime; never in the shipped library.
 __device__ unsigned long long g_stamp[64][8];
+__device__ unsigned long long g_stamp3[64][16][4];   // per wave, absolute s_memtime: kernel entry, loads issued, after the first barrier, first task drawn
 __device__ unsigned long long g_stamp2[64][16][3];   // per wave: tasks, poll cycles, work cycles
 #define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long _t; \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); \
@@ -1108,6 +1110,38 @@ __device__ __forceinline__ uint32_t pack_record(int ax, int ay, const Dyn &d, in
            ((uint32_t)(truncated != 0) << 29);
 }
 
+// Per-engine constant tables of the pipelined kernel, built once at tw_create: what every workgroup used to recompute
+// in its prologue (1155 + 292 + 76 image words per wave with index divisions, and make_obs_fast's divisions by the
+// runtime view size) -- at 1024 envs per GPU the prologue was 21 % of the kernel (30 of 142 k cycles), at 4096 still 10 %.
+//   [PT_IMG, +ENV_WORDS)   the static wall-padded code image | float matrix image | matrix code bytes of an empty map
+//   [PT_OBS, +2*64*16)     ObsFast of lane l for the two-stream layout (chunk = l) and the record layout (chunk = l - 9):
+//                          words 0-5 rel4, 6 shift, 7-10 andm, 11-14 orm, 15 active
+constexpr int PT_IMG = 0, PT_OBS = ENV_WORDS, PT_WORDS = PT_OBS + 2 * 64 * 16;
+static_assert(ENV_WORDS % 4 == 0 && ENV_WORDS / 4 <= 6 * 64, "image copied as 6 x dwordx4 per lane");
+
+__global__ __launch_bounds__(64) void tw_pipe_tables_kernel(uint32_t *tab, int V) {
+    const int lane = threadIdx.x;
+    uint32_t *im = tab + PT_IMG;
+    for (int i = lane; i < ENV_WORDS; i += 64) im[i] = 0u;
+    __syncthreads();
+    for (int i = lane; i < GP_WORDS; i += 64) {
+        const int x = i / GPP - GPX0, y = i - (i / GPP) * GPP - GPY0;
+        im[i] = inb(x, y) ? static_cell(x, y) : C_WALL;
+    }
+    for (int c = lane; c < MAT_WORDS; c += 64)
+        im[MAT_OFF + c] = c < NC ? mat_of_code(static_cell(c - (c / GS) * GS, c / GS)) : 0u;
+    for (int c = lane; c < MATC_BYTES; c += 64)
+        mcb(im)[c] = c < NC ? mcode_of(mat_of_code(static_cell(c - (c / GS) * GS, c / GS))) : 0;
+    for (int r = 0; r < 2; ++r) {
+        const ObsFast f = make_obs_fast(r ? lane - 9 : lane, V);
+        uint32_t *o = tab + PT_OBS + (r * 64 + lane) * 16;
+        for (int k = 0; k < 6; ++k) o[k] = (uint32_t)f.rel4[k];
+        o[6] = f.shift;
+        for (int k = 0; k < 4; ++k) { o[7 + k] = f.andm[k]; o[11 + k] = f.orm[k]; }
+        o[15] = (uint32_t)f.active;
+    }
+}
+
 template <int VARIANT, int PG>
 __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t pipe_lds[];
@@ -1119,52 +1153,96 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
 
     constexpr bool V4 = VARIANT == 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int N = p.n_envs, V = p.view;
+    const int N = p.n_envs;
+#ifdef TW_STAMP
+    unsigned long long pst_entry = 0, pst_lstart = 0, pst_lend = 0, pst_p1 = 0, pst_p2 = 0, pst_p3 = 0, pst_p4 = 0;
+#define PSTAMP0(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory")
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pst_entry) :: "memory");
+#endif
     // workgroups are dealt round-robin to the 8 XCDs: give each XCD one contiguous range of envs so that the
     // partially written lines of the [T][N] scalar outputs (reward / terminated / truncated / pos) merge in ONE L2
     const int n0 = ((gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x) * PG;
     uint32_t *my_img = img + wave * ENV_WORDS;
 
-    // ---- private static image per wave; records of the block's envs
-    for (int i = lane; i < GP_WORDS; i += 64) {
-        const int x = i / GPP - GPX0, y = i - (i / GPP) * GPP - GPY0;
-        my_img[i] = inb(x, y) ? static_cell(x, y) : C_WALL;
+    // ---- every global load of the prologue is issued up front and UNCONDITIONALLY (clamped indices instead of
+    // predicates: a predicated load becomes a branch with its own wait) -- ONE HBM round trip instead of three:
+    //   * the static image goes from the per-engine table straight into this wave's LDS copy (LDS-direct loads, no VGPRs;
+    //     lane l of chunk k lands at my_img + 16 (64 k + l) bytes),
+    //   * this lane's emission constants (same table), the block's records, the planes to verify, the first chunk's actions.
+    const bool record = p.record != 0;
+    const uint4 *tab4 = reinterpret_cast<const uint4 *>(p.pipe_tab);
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+        if (lane + 64 * k < ENV_WORDS / 4)
+            __builtin_amdgcn_global_load_lds(tab4 + lane + 64 * k,
+                                             (__attribute__((address_space(3))) void *)(my_img + 256 * k), 16, 0, 0);
+    const uint4 *of4 = tab4 + PT_OBS / 4 + ((record ? 64 : 0) + lane) * 4;
+    const uint4 ofw0 = of4[0], ofw1 = of4[1], ofw2 = of4[2], ofw3 = of4[3];
+    const bool own_env = wave < PG && n0 + wave < N;              // wave e loads and verifies env n0 + e
+    const int ve = min(n0 + (wave < PG ? wave : 0), N - 1);
+    const int32_t rec_pre = p.rec[(size_t)ve * REC + (lane < REC ? lane : 0)];
+    uint32_t ty_pre[5], co_pre[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const size_t g = (size_t)ve * NC + min(lane + 64 * k, NC - 1);
+        ty_pre[k] = p.type[g]; co_pre[k] = p.colour[g];
     }
-    for (int c = lane; c < MAT_WORDS; c += 64)
-        my_img[MAT_OFF + c] = c < NC ? mat_of_code(static_cell(c - (c / GS) * GS, c / GS)) : 0u;
-    for (int c = lane; c < MATC_BYTES; c += 64)
-        mcb(my_img)[c] = c < NC ? mcode_of(mat_of_code(static_cell(c - (c / GS) * GS, c / GS))) : 0;
+    constexpr int NPRE = (PCH * PG + 64 * PWAVES - 1) / (64 * PWAVES);   // staging items per thread and chunk
+    int act_pre[NPRE];
+    {
+        const int len0 = min(PCH, p.T);
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            const int i = tid + k * 64 * PWAVES, tl = i / PG, e = i - tl * PG;
+            act_pre[k] = p.actions[(size_t)min(tl, len0 - 1) * N + min(n0 + e, N - 1)];
+        }
+    }
+#ifdef TW_STAMP
+    PSTAMP0(pst_p1);
+    if (lane == 0 && blockIdx.x < 64) { g_stamp3[blockIdx.x][wave][0] = pst_entry; g_stamp3[blockIdx.x][wave][1] = pst_p1; }
+#endif
+    // ---- records of the block's envs; the image copies must have landed before anyone patches the image
     const bool code_mode = (p.flags & TW_F_MATRIX_CODE) != 0;
     uint8_t *img_bytes = reinterpret_cast<uint8_t *>(my_img);
-    if (wave < PG && lane < REC) recs[wave * REC + lane] = (n0 + wave < N) ? p.rec[(size_t)(n0 + wave) * REC + lane] : 0;
+    if (wave < PG && lane < REC) recs[wave * REC + lane] = own_env ? rec_pre : 0;
     if (tid == 0) { ctrl[0] = 0; ctrl[1] = 0; }
     if (blockIdx.x == 0 && tid == 0) *p.abnormal_other = 0;     // stream order: the previous launch's fallback is done
+    __builtin_amdgcn_s_waitcnt(0x0f70);                           // vmcnt(0): LDS-direct loads retire through the vector-memory counter
     __syncthreads();
 
-    // ---- wave e verifies env n0+e: scalar regime + planes == closed form
+#ifdef TW_STAMP
+    PSTAMP0(pst_p2);
+    if (lane == 0 && blockIdx.x < 64) g_stamp3[blockIdx.x][wave][2] = pst_p2;
+#endif
+    // ---- wave e verifies env n0+e: scalar regime + planes == closed form (plane bytes: loaded above)
     {
         EnvS s;
         load_env(s, recs + (wave < PG ? wave : 0) * REC);
         bool ok = true;
-        if (wave < PG && n0 + wave < N) {
+        if (own_env) {
             ok = pipe_state_ok<V4>(s);
             Dyn d = {s.obx[0], s.pone, s.wall_i1, s.wall_i2, s.patrol, s.o1y[0], s.o2x[0]};
-            const size_t gb = (size_t)(n0 + wave) * NC;
-            for (int c = lane; c < NC; c += 64) {
-                const uint32_t want = analytic_cell(c - (c / GS) * GS, c / GS, d);
-                const uint32_t have = (uint32_t)p.type[gb + c] | ((uint32_t)p.colour[gb + c] << 8);
-                ok &= (want == have);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int c = lane + 64 * k;
+                if (c < NC) ok &= analytic_cell(c - (c / GS) * GS, c / GS, d) == (ty_pre[k] | (co_pre[k] << 8));
             }
         }
         if (__ballot(!ok) != 0ull && lane == 0) atomicOr(p.abnormal, 1);
     }
-    __syncthreads();
 
+#ifdef TW_STAMP
+    PSTAMP0(pst_p3);
+#endif
     // ---- emission constants of this lane.  Record layout (tw_alloc_outputs): the env-step's 2048-byte block is
     // written by exactly two full-wave stores of eight whole 128-byte lines each -- lanes 0..63 matrix floats 0..255,
     // then lanes 0..8 matrix floats 256..291 and lanes 9..63 the 55 image chunks.
-    const bool record = p.record != 0;
-    const ObsFast of = make_obs_fast(record ? lane - 9 : lane, V);
+    ObsFast of;
+    of.rel4[0] = (int)ofw0.x; of.rel4[1] = (int)ofw0.y; of.rel4[2] = (int)ofw0.z; of.rel4[3] = (int)ofw0.w;
+    of.rel4[4] = (int)ofw1.x; of.rel4[5] = (int)ofw1.y; of.shift = ofw1.z;
+    of.andm[0] = ofw1.w; of.andm[1] = ofw2.x; of.andm[2] = ofw2.y; of.andm[3] = ofw2.z;
+    of.orm[0] = ofw2.w; of.orm[1] = ofw3.x; of.orm[2] = ofw3.y; of.orm[3] = ofw3.z;
+    of.active = (int)ofw3.w; of.chunk = of.active ? (record ? lane - 9 : lane) : 0;
     // dynamic-cell slot of this lane: 0-2 balls, 3-10 wall blocks, 11-13 patrol column, 14-17 patrol square
     // Every lane decodes the packed record for itself with per-lane shift/mask constants (the scalar unit is
     // shared by the CU's four SIMDs and was the emission waves' bottleneck):
@@ -1248,13 +1326,19 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
     }
     const bool policy_idx = (p.flags & TW_F_POLICY_IDX) != 0;
 
+#ifdef TW_STAMP
+    PSTAMP0(pst_p4);
+#endif
     for (int c0 = 0; c0 < p.T; c0 += PCH) {
         const int len = min(PCH, p.T - c0);
         // the chunk's actions go to LDS up front: the logic wave must never wait on vmcnt (on gfx950 a load
         // retires behind every older store, and the emit waves keep the write queues full)
-        for (int i = tid; i < len * PG; i += 64 * PWAVES) {
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            const int i = tid + k * 64 * PWAVES;
+            if (i >= len * PG) break;
             const int tl = i / PG, e = i - tl * PG;
-            const int act_in = (n0 + e < N) ? p.actions[(size_t)(c0 + tl) * N + n0 + e] : 0;
+            const int act_in = (n0 + e < N) ? (c0 == 0 ? act_pre[k] : p.actions[(size_t)(c0 + tl) * N + n0 + e]) : 0;
             ring[i] = (n0 + e < N) ? 0u : REC_VALID;        // padding envs of a ragged last block are "done" from the start
             // The draw counter of an env advances by one per step whatever happens, so every Philox word of
             // the chunk is known up front: all 16 waves compute them in parallel and the serial logic wave
@@ -1414,6 +1498,8 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
             PSTAMP(pst_t1);
 #ifdef TW_STAMP
             pst_l = pst_t1 - pst_t0;
+            if (c0 == 0) pst_lstart = pst_t0;
+            pst_lend = pst_t1;
             if (lane == 0 && blockIdx.x < 64) g_stamp[blockIdx.x][0] = pst_l;
 #endif
         }
@@ -1586,6 +1672,19 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
             p.colour_out[gb + c] = (uint8_t)(v >> 8);
         }
     }
+#ifdef TW_STAMP
+    if (wave == 0) {
+        unsigned long long pst_exit;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pst_exit) :: "memory");
+        if (lane == 0 && blockIdx.x < 64) {
+            g_stamp[blockIdx.x][4] = pst_lstart - pst_entry;       // prologue: images, verification, staging
+            g_stamp[blockIdx.x][5] = pst_exit - pst_lend;          // from the logic wave's last record to the kernel's end
+            g_stamp[blockIdx.x][6] = pst_exit - pst_entry;         // whole kernel as wave 0 sees it
+            g_stamp2[blockIdx.x][0][0] = pst_p1 - pst_entry; g_stamp2[blockIdx.x][0][1] = pst_p2 - pst_p1;
+            g_stamp2[blockIdx.x][0][2] = pst_p3 - pst_p2; g_stamp2[blockIdx.x][1][0] = pst_p4 - pst_p3; g_stamp2[blockIdx.x][1][1] = pst_lstart - pst_p4;
+        }
+    }
+#endif
 }
 
 // ---------------------------------------------------------------- init / reset / obs-only kernels (wave per env)
@@ -1669,6 +1768,7 @@ struct tw_engine {
     int pipeline;                   // 1 = use the pipelined kernel when eligible (TW_PIPELINE=0 disables)
     int *fb_count;                  // device counter: pipelined launches re-run by the sequential fallback
     int slab_backing;               // how tw_alloc_outputs backs its slab (0 hipMalloc, 1 mapped 2 MiB granules, ...)
+    uint32_t *pipe_tab;             // constant tables of the pipelined kernel (static image, per-lane emission constants)
 };
 
 namespace {
@@ -1698,6 +1798,7 @@ Params base_params(const tw_engine *e) {
     p.type_out = e->type; p.colour_out = e->colour; p.rec_out = e->rec;
     p.abnormal = e->abnormal; p.abnormal_other = e->abnormal + 1; p.only_if_flagged = 0;
     p.fb_count = e->fb_count;
+    p.pipe_tab = e->pipe_tab;
     p.n_envs = e->n_envs; p.view = e->view; p.variant = e->variant;
     p.seed_lo = (uint32_t)e->seed; p.seed_hi = (uint32_t)(e->seed >> 32);
     p.env_id0 = e->env_id0;
@@ -1817,7 +1918,7 @@ int tw_create(tw_engine **out, int variant, int n_envs, int view_size, int devic
     const char *pl = getenv("TW_PIPELINE");
     e->pipeline = pl ? atoi(pl) : 1;
     e->slab_backing = 1;            // 2 MiB chunks created one by one, mapped in creation order (see slab_alloc)
-    hipError_t rr[7];
+    hipError_t rr[8];
     rr[0] = hipMalloc((void **)&e->type, (size_t)n_envs * NC);
     rr[1] = hipMalloc((void **)&e->colour, (size_t)n_envs * NC);
     rr[2] = hipMalloc((void **)&e->rec, (size_t)n_envs * REC * sizeof(int32_t));
@@ -1825,7 +1926,8 @@ int tw_create(tw_engine **out, int variant, int n_envs, int view_size, int devic
     rr[4] = hipMalloc((void **)&e->colour2, (size_t)n_envs * NC);
     rr[5] = hipMalloc((void **)&e->rec2, (size_t)n_envs * REC * sizeof(int32_t));
     rr[6] = hipMalloc((void **)&e->abnormal, 3 * sizeof(int));
-    for (int i = 0; i < 7; ++i)
+    rr[7] = hipMalloc((void **)&e->pipe_tab, (size_t)PT_WORDS * sizeof(uint32_t));
+    for (int i = 0; i < 8; ++i)
         if (rr[i] != hipSuccess) { hipError_t bad = rr[i]; tw_destroy(e); return hip_fail(bad); }
     {
         hipError_t me = hipMemset(e->abnormal, 0, 3 * sizeof(int));
@@ -1843,6 +1945,7 @@ int tw_create(tw_engine **out, int variant, int n_envs, int view_size, int devic
                 e->pipeline = 0;
     }
     Params p = base_params(e);
+    hipLaunchKernelGGL(tw_pipe_tables_kernel, dim3(1), dim3(64), 0, 0, e->pipe_tab, e->view);
     hipLaunchKernelGGL(tw_reset_kernel, dim3(n_envs), dim3(64), 0, 0, p, (const uint8_t *)nullptr, 0);
     hipError_t le = hipGetLastError();
     if (le == hipSuccess) le = hipStreamSynchronize(0);
@@ -1861,6 +1964,7 @@ int tw_destroy(tw_engine *e) {
     if (e->colour2) (void)hipFree(e->colour2);
     if (e->rec2) (void)hipFree(e->rec2);
     if (e->abnormal) (void)hipFree(e->abnormal);
+    if (e->pipe_tab) (void)hipFree(e->pipe_tab);
     free(e);
     return TW_OK;
 }
@@ -1971,6 +2075,9 @@ int tw_gen_obs(tw_engine *e, int view_size, uint8_t *obs, int obs_pitch, void *s
 #ifdef TW_STAMP
 int tw_debug_stamps2(unsigned long long *out3072) {
     return hipMemcpyFromSymbol(out3072, HIP_SYMBOL(g_stamp2), sizeof(unsigned long long) * 3072) == hipSuccess ? 0 : -2;
+}
+int tw_debug_stamps3(unsigned long long *out4096) {
+    return hipMemcpyFromSymbol(out4096, HIP_SYMBOL(g_stamp3), sizeof(unsigned long long) * 4096) == hipSuccess ? 0 : -2;
 }
 int tw_debug_stamps(unsigned long long *out512) {
     return hipMemcpyFromSymbol(out512, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 512) == hipSuccess ? 0 : -2;

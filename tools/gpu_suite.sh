@@ -1,3 +1,8 @@
+#!/bin/bash
+# The whole GPU suite on one box (unbuffered: a silent run is taken for hung after 7 minutes).
+export PYTHONUNBUFFERED=1
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-timeout -k 10 1100 python -m pytest tests -m gpu -x -q --durations=12 > gpurun_out/r2_suite.log 2>&1; rc=$?
-tail -25 gpurun_out/r2_suite.log; exit $rc
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 || exit 1
+timeout -k 10 1100 python -u -m pytest tests -m gpu -x -q --durations=8 2>&1 | tee gpurun_out/suite.log | grep -v "^$" | tail -25
+exit ${PIPESTATUS[0]}
