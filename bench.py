@@ -376,12 +376,13 @@ def run_engine_mode(args, rank, world, dev, coll):
     run(0, 8)
     ew1.record()
     torch.cuda.synchronize()
-    est_ms = max(ew0.elapsed_time(ew1) / 8.0, 1e-3)
+    # every rank must run the same number of regions (each one has barriers): agree on the slowest rank's estimate
+    est_ms = max_over_ranks(max(ew0.elapsed_time(ew1) / 8.0, 1e-3), dev, world)
     warm_launches = 8 + int(50.0 / est_ms) + 1
     run(0, warm_launches - 8)
     # R timed regions of exactly K launches each, every one bracketed by barrier + synchronize on both sides; the line
     # reports the MEDIAN region (value, ms_per_step, roofline.kernel_ms) and the spread of all of them
-    R = args.regions if args.regions > 0 else max(25, int(110.0 / (K * est_ms)) + 1)
+    R = args.regions if args.regions > 0 else min(400, max(25, int(110.0 / (K * est_ms)) + 1))
     wall_s, ev_ms_all = [], []
     for r_ in range(R):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

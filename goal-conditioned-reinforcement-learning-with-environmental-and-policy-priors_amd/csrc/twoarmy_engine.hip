@@ -1557,20 +1557,26 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
                 const int bidx = pre ? MATC_OFF * 4 + y * GS + x : trash_g * 4;       // byte image of the matrix codes
                 const int bca = lane == 0 ? MATC_OFF * 4 + ay * GS + ax : trash_g * 4;
                 my_img[gidx] = dc_code;                                  // unconditional: idle lanes hit their trash word
-                my_img[midx] = dc_mval;
-                if (code_mode) img_bytes[bidx] = dc_mcode;
+                // code frames never touch the float matrix image, float frames never the code bytes (the emission is
+                // issue-bound with code frames: every LDS operation saved counts)
+                if (code_mode) img_bytes[bidx] = dc_mcode; else my_img[midx] = dc_mval;
                 wave_sync();
                 if ((((r >> 21) ^ (r >> 22)) & 5u) == 0u) {
                     // common case: obs and matrix see the same grid -> one batch of gathers, then pack + store
-                    my_img[lane == 0 ? ca : trash_g] = M_AGENT;           // after the dynamic cells: the agent wins (0.3)
-                    if (code_mode) img_bytes[bca] = 3;
+                    if (code_mode) img_bytes[bca] = 3;                    // after the dynamic cells: the agent wins (0.3 / code 3)
+                    else my_img[lane == 0 ? ca : trash_g] = M_AGENT;
                     wave_sync();
                     const char *base = reinterpret_cast<const char *>(my_img + gpi(ax, ay));
                     uint32_t c[6];
 #pragma unroll
                     for (int k = 0; k < 6; ++k) c[k] = *reinterpret_cast<const uint32_t *>(base + of.rel4[k]);
-                    const uint4 m0 = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(my_img) + mat_lane_off);
-                    const uint4 m1 = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(my_img) + mat_laneb_off);
+                    uint4 m0 = make_uint4(0u, 0u, 0u, 0u), m1 = m0;
+                    if (code_mode) {
+                        m0 = *reinterpret_cast<const uint4 *>(img_bytes + MATC_OFF * 4 + 16 * (lane < MATC_BYTES / 16 ? lane : 0));
+                    } else {
+                        m0 = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(my_img) + mat_lane_off);
+                        m1 = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(my_img) + mat_laneb_off);
+                    }
                     const uint32_t w0 = c[0] | (c[1] << 24), w1 = (c[1] >> 8) | (c[2] << 16), w2 = (c[2] >> 16) | (c[3] << 8);
                     const uint32_t w3 = c[4] | (c[5] << 24), w4 = c[5] >> 8;
                     uint4 o;
@@ -1591,17 +1597,14 @@ __global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
                         if (lane < 9) store16(mat_dst + 4 * (64 + lane), m1);
                     } else {
                         if (of.active) store16(obs_dst + 16 * lane, o);
-                        if (lane < MATC_BYTES / 16)
-                            *reinterpret_cast<uint4 *>(matc_dst + 16 * lane) =
-                                *reinterpret_cast<const uint4 *>(img_bytes + MATC_OFF * 4 + 16 * lane);
+                        if (lane < MATC_BYTES / 16) store16(matc_dst + 16 * lane, m0);
                     }
                     wave_sync();
                     my_img[gidx] = C_EMPTY;                               // un-patch (trash words may hold anything)
-                    my_img[midx] = M_FREE;
-                    if (code_mode) img_bytes[bidx] = 0;
+                    if (code_mode) img_bytes[bidx] = 0; else my_img[midx] = M_FREE;
                     wave_sync();
-                    my_img[lane == 0 ? ca : trash_g] = M_FREE;            // the agent only ever stands on free / goal / ball cells
-                    if (code_mode) img_bytes[bca] = 0;
+                    if (code_mode) img_bytes[bca] = 0;                    // the agent only ever stands on free / goal / ball cells
+                    else my_img[lane == 0 ? ca : trash_g] = M_FREE;
                 } else {
                     // wall drop / patrol spawn happened in this very step: the matrix sees it, the observation did not
                     const bool post = (dc_always | ((r >> dc_postbit) & dc_fmask)) != 0u;

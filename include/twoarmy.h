@@ -167,8 +167,12 @@ const char *tw_build_id(void);
  * stream is 0.19-0.20 ms on every allocation.)
  *   pos float[T][N][2], reward float[T][N], terminated / truncated uint8[T][N]   (dense)
  * `backing`: how the slab is backed -- 1 (default) = 2 MiB physical chunks (hipMemCreate) mapped into one virtual range,
- * 0 = hipMalloc (also the fallback when the runtime refuses the mapping calls).  Pass the struct's members to tw_step / tw_rollout.  tw_free_outputs releases the slab
- * (the struct is zeroed). */
+ * 0 = hipMalloc (also the fallback when the runtime refuses the mapping calls).  Pass the struct's members to tw_step /
+ * tw_rollout.  tw_free_outputs returns the slab's physical memory (the struct is zeroed) but keeps a mapped slab's VIRTUAL
+ * address range reserved for the life of the process -- slab_bytes of address space per released slab (about 1 GiB at
+ * 4096 envs x 128 steps), nothing else: on ROCm 7.2 a range that went through hipMemAddressFree and was handed out again
+ * by hipMemAddressReserve is read wrongly by hipMemcpy device -> host (tools/vmm_reuse_repro.hip).  Allocate output slabs
+ * once and reuse them; a process that allocates and frees slabs in a loop only spends address space. */
 typedef struct tw_outputs {
     uint8_t *obs;
     void *matrix;
