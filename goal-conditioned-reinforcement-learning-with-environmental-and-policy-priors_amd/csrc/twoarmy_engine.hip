@@ -1027,8 +1027,15 @@ __global__ __launch_bounds__(64, (E == 1 ? 4 : 2)) void tw_rollout_kernel(Params
 // Anything outside normal play (illegal action, drifted balls, injected grids, ...) raises *p.abnormal;
 // the host always enqueues the sequential kernel behind this one, which re-runs the launch from the
 // untouched input state iff the flag is set (both write the `_out` state; the host swaps afterwards).
-constexpr int PG_MAX = 16;      // envs per workgroup (template parameter PG = 16, 8, 4 or 2: small batches still fill the CUs)
-constexpr int PWAVES = 16;      // waves per workgroup
+#ifndef TW_PWAVES
+#define TW_PWAVES 16
+#endif
+#ifndef TW_WG_TARGET
+#define TW_WG_TARGET 256
+#endif
+constexpr int PWAVES = TW_PWAVES;   // waves per workgroup (wave e verifies env e of the group: PG <= PWAVES)
+constexpr int PG_MAX = PWAVES < 16 ? PWAVES : 16;   // envs per workgroup (template parameter PG = 16, 8, 4 or 2: small batches still fill the CUs)
+constexpr int PIPE_WG_TARGET = TW_WG_TARGET;        // envs per workgroup are chosen so that about this many workgroups exist
 constexpr int PCH = 128;        // steps per ring chunk
 // env-steps one emission wave takes per draw from the task counter.  1: the 16 waves of a workgroup then write 16
 // neighbouring rows of the same step at any time.  With 8 (one wave streaming 16 KB on its own) the same stores ran
@@ -1143,7 +1150,7 @@ __global__ __launch_bounds__(64) void tw_pipe_tables_kernel(uint32_t *tab, int V
 }
 
 template <int VARIANT, int PG>
-__global__ __launch_bounds__(1024) void tw_pipe_kernel(Params p) {
+__global__ __launch_bounds__(64 * PWAVES, 16 / PWAVES) void tw_pipe_kernel(Params p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t pipe_lds[];
     uint32_t *img = pipe_lds;                                   // [PWAVES][ENV_WORDS]
     uint32_t *ring = img + PWAVES * ENV_WORDS;                  // [PCH][PG]
@@ -1880,7 +1887,12 @@ int launch_rollout(tw_engine *e, int T, const int32_t *actions, const uint32_t *
     e->parity ^= 1;
     // envs per workgroup: 16 from 4096 envs up; fewer for small batches so that ~256 workgroups exist (one per CU)
     int pg = 2;
-    while (pg < PG_MAX && (e->n_envs + pg - 1) / pg > 256) pg <<= 1;
+    while (pg < PG_MAX && (e->n_envs + pg - 1) / pg > PIPE_WG_TARGET) pg <<= 1;
+    // One round of 16-env workgroups keeps the whole chip in lock step: every CU in its prologue, then every CU storing,
+    // then every CU in its tail.  Two rounds of 8-env workgroups desynchronise the CUs after the first round (measured
+    // at 4096 envs, v6: 3-4 % faster on two boxes, v4: equal; from 8192 envs up the 16-env groups already make several
+    // rounds, below ~2000 envs a second round would double the logic chain, which bounds the launch there).
+    if (pg == 16 && (e->n_envs + 15) / 16 <= PIPE_WG_TARGET) pg = 8;
     const int grid = (e->n_envs + pg - 1) / pg;
 #define TW_PIPE_LAUNCH(VAR, PGV) \
     hipLaunchKernelGGL((tw_pipe_kernel<VAR, PGV>), dim3(grid), dim3(64 * PWAVES), PIPE_LDS_BYTES, st, p)
@@ -1894,7 +1906,11 @@ int launch_rollout(tw_engine *e, int T, const int32_t *actions, const uint32_t *
 #undef TW_PIPE_LAUNCH
     HIP_TRY(hipGetLastError());
     p.only_if_flagged = 1;
+#ifdef TW_DEBUG_NO_FALLBACK_LAUNCH
+    int rc = TW_OK;                              // diagnostic build only: what the flag-gated launch costs
+#else
     int rc = launch_sequential(e, p, st);
+#endif
     if (rc != TW_OK) return rc;
     uint8_t *t8; int32_t *t32;
     t8 = e->type; e->type = e->type2; e->type2 = t8;

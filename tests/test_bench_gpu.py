@@ -40,3 +40,17 @@ def test_two_ranks_on_one_gpu_through_the_launcher():
     assert r["n_gpus"] == 2
     c = r["config"]["collective"]
     assert c["world_size"] == 2 and c["sanity_allreduce_of_ones"] == 2.0
+
+
+def test_two_ranks_ppo_mode_zero_copy_bucket():
+    """--mode ppo on two ranks (they share the GPU: gloo): every optimiser step issues two all-reduces (actor's while the
+    critic's backward runs, then the critic's), nothing is copied into the bucket, the line carries the bucket's timings."""
+    r = _bench(["--gpus", "2", "--mode", "ppo", "--variant", "v4", "--envs", "256", "--minibatch", "8192", "--k-epochs", "2",
+                "--steps", "1", "--warmup", "1", "--graph", "off"], timeout=900)
+    assert r["n_gpus"] == 2 and r["dtype"] == "f32"
+    gb = r["config"]["grad_bucket"]
+    steps = gb["optimiser_steps_per_iteration"]
+    assert steps == 2 * 4                                        # 256 x 128 samples / 8192 per minibatch, K = 2
+    assert gb["allreduces_issued"] == 2 * steps and gb["gradients_copied_into_bucket"] == 0
+    assert gb["floats"] == 2515206 and gb["ms_per_allreduce"] > 0 and gb["ms_exposed_per_optimiser_step_mean"] > 0
+    assert r["config"]["slab_backing"]["agree"] is True
