@@ -15,6 +15,8 @@ from twoarmy_amd import _lib, engine as eng_mod  # noqa
 
 T, N = 128, int(os.environ.get("AB_ENVS", "4096"))
 VARIANT = int(os.environ.get("AB_VARIANT", "6"))
+CODES = os.environ.get("AB_CODES", "0") == "1"          # uint8 code frames (TW_F_MATRIX_CODE)
+VIEW = int(os.environ.get("AB_VIEW", "17"))
 names = sys.argv[1:] or ["std"]
 engines = []
 base = _lib.LIB_PATH
@@ -22,9 +24,9 @@ for nm in names:
     _lib._lib = None
     _lib.LIB_PATH = base if nm == "std" else os.path.join(os.path.dirname(base), "libtwoarmy_hip_%s.so" % nm)
     lib = _lib.lib()                                    # binds signatures on this handle
-    e = eng_mod.TwoarmyEngine(VARIANT, N, 17, seed=9981)
+    e = eng_mod.TwoarmyEngine(VARIANT, N, VIEW, seed=9981)
     shared = engines[0][4] if engines and os.environ.get("AB_SHARED_OUTPUTS", "1") == "1" else None
-    engines.append((nm, lib, e, e.fill_actions(T), shared if shared is not None else e.alloc_outputs(T)))
+    engines.append((nm, lib, e, e.fill_actions(T), shared if shared is not None else e.alloc_outputs(T, matrix_codes=CODES)))
     o = engines[-1][4]
     print("%-8s obs %#x matrix %#x pos %#x reward %#x (matrix - obs = %d MiB + %d B)" % (
         nm, o["obs"].data_ptr(), o["matrix"].data_ptr(), o["pos"].data_ptr(), o["reward"].data_ptr(),
