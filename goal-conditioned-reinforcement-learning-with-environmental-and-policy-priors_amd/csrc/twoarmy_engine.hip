@@ -1037,15 +1037,18 @@ constexpr int PWAVES = TW_PWAVES;   // waves per workgroup (wave e verifies env 
 constexpr int PG_MAX = PWAVES < 16 ? PWAVES : 16;   // envs per workgroup (template parameter PG = 16, 8, 4 or 2: small batches still fill the CUs)
 constexpr int PIPE_WG_TARGET = TW_WG_TARGET;        // envs per workgroup are chosen so that about this many workgroups exist
 constexpr int PCH = 128;        // steps per ring chunk
-// env-steps one emission wave takes per draw from the task counter.  1: the 16 waves of a workgroup then write 16
-// neighbouring rows of the same step at any time.  With 8 (one wave streaming 16 KB on its own) the same stores ran
-// 5-17 % slower on every box tried, and a store-only replica of the pattern (tools/store_pattern_probe.hip) drops
-// from ~6.3 to ~4.3 TB/s: the kernel is bound by the store path, not by issue (all compute without the stores: 99 us
-// of 239).
-#ifndef TW_PGRP
-#define TW_PGRP 1
+// env-steps one emission wave takes per draw from the task counter: a compile-time choice per frame layout.
+// Float frames: 1 -- the 16 waves of a workgroup then write 16 neighbouring rows of the same step at any time; with 8 (one
+// wave streaming 16 KB on its own) the same stores ran 5-17 % slower on every box tried, with 2 still 5 % slower, and a
+// store-only replica of the pattern (tools/store_pattern_probe.hip) drops from ~6.3 to ~4.3 TB/s: that layout is bound by
+// the store path, not by issue.  Code frames (TW_F_MATRIX_CODE, 1184-byte records) are issue-bound instead: 4 tasks per
+// draw save three of four counter / poll / index sequences (6 % per launch, tools/ab_variants.py with AB_CODES=1), and the
+// code-frame instantiation of the kernel drops every float-matrix path at compile time.
+#ifdef TW_PGRP
+constexpr int PGRP_FLOAT = TW_PGRP, PGRP_CODE = TW_PGRP;      // diagnostic builds: one value for both layouts
+#else
+constexpr int PGRP_FLOAT = 1, PGRP_CODE = 4;
 #endif
-constexpr int PGRP = TW_PGRP;
 constexpr uint32_t REC_VALID = 0x80000000u;
 
 struct Dyn { int b0, pone, i1, i2, patrol, o1y0, o2x0; };
@@ -1149,8 +1152,9 @@ __global__ __launch_bounds__(64) void tw_pipe_tables_kernel(uint32_t *tab, int V
     }
 }
 
-template <int VARIANT, int PG>
+template <int VARIANT, int PG, bool CODE>
 __global__ __launch_bounds__(64 * PWAVES, 16 / PWAVES) void tw_pipe_kernel(Params p) {
+    constexpr int PGRP = (CODE ? PGRP_CODE : PGRP_FLOAT) < PG ? (CODE ? PGRP_CODE : PGRP_FLOAT) : PG;
     extern __shared__ __attribute__((aligned(16))) uint32_t pipe_lds[];
     uint32_t *img = pipe_lds;                                   // [PWAVES][ENV_WORDS]
     uint32_t *ring = img + PWAVES * ENV_WORDS;                  // [PCH][PG]
@@ -1209,7 +1213,7 @@ __global__ __launch_bounds__(64 * PWAVES, 16 / PWAVES) void tw_pipe_kernel(Param
     if (lane == 0 && blockIdx.x < 64) { g_stamp3[blockIdx.x][wave][0] = pst_entry; g_stamp3[blockIdx.x][wave][1] = pst_p1; }
 #endif
     // ---- records of the block's envs; the image copies must have landed before anyone patches the image
-    const bool code_mode = (p.flags & TW_F_MATRIX_CODE) != 0;
+    constexpr bool code_mode = CODE;                            // == (p.flags & TW_F_MATRIX_CODE) != 0: the host picks the instantiation
     uint8_t *img_bytes = reinterpret_cast<uint8_t *>(my_img);
     if (wave < PG && lane < REC) recs[wave * REC + lane] = own_env ? rec_pre : 0;
     if (tid == 0) { ctrl[0] = 0; ctrl[1] = 0; }
@@ -1894,15 +1898,15 @@ int launch_rollout(tw_engine *e, int T, const int32_t *actions, const uint32_t *
     // rounds, below ~2000 envs a second round would double the logic chain, which bounds the launch there).
     if (pg == 16 && (e->n_envs + 15) / 16 <= PIPE_WG_TARGET) pg = 8;
     const int grid = (e->n_envs + pg - 1) / pg;
-#define TW_PIPE_LAUNCH(VAR, PGV) \
-    hipLaunchKernelGGL((tw_pipe_kernel<VAR, PGV>), dim3(grid), dim3(64 * PWAVES), PIPE_LDS_BYTES, st, p)
-    if (e->variant == 4) {
-        if (pg == 16) TW_PIPE_LAUNCH(4, 16); else if (pg == 8) TW_PIPE_LAUNCH(4, 8);
-        else if (pg == 4) TW_PIPE_LAUNCH(4, 4); else TW_PIPE_LAUNCH(4, 2);
-    } else {
-        if (pg == 16) TW_PIPE_LAUNCH(6, 16); else if (pg == 8) TW_PIPE_LAUNCH(6, 8);
-        else if (pg == 4) TW_PIPE_LAUNCH(6, 4); else TW_PIPE_LAUNCH(6, 2);
-    }
+#define TW_PIPE_LAUNCH(VAR, PGV, CD) \
+    hipLaunchKernelGGL((tw_pipe_kernel<VAR, PGV, CD>), dim3(grid), dim3(64 * PWAVES), PIPE_LDS_BYTES, st, p)
+#define TW_PIPE_LAUNCH_PG(VAR, CD) do { \
+        if (pg == 16) TW_PIPE_LAUNCH(VAR, 16, CD); else if (pg == 8) TW_PIPE_LAUNCH(VAR, 8, CD); \
+        else if (pg == 4) TW_PIPE_LAUNCH(VAR, 4, CD); else TW_PIPE_LAUNCH(VAR, 2, CD); } while (0)
+    const bool codes = (flags & TW_F_MATRIX_CODE) != 0;
+    if (e->variant == 4) { if (codes) TW_PIPE_LAUNCH_PG(4, true); else TW_PIPE_LAUNCH_PG(4, false); }
+    else { if (codes) TW_PIPE_LAUNCH_PG(6, true); else TW_PIPE_LAUNCH_PG(6, false); }
+#undef TW_PIPE_LAUNCH_PG
 #undef TW_PIPE_LAUNCH
     HIP_TRY(hipGetLastError());
     p.only_if_flagged = 1;
@@ -1954,11 +1958,10 @@ int tw_create(tw_engine **out, int variant, int n_envs, int view_size, int devic
         if (me != hipSuccess) { tw_destroy(e); return hip_fail(me); }
     }
     {   // the pipelined kernel needs > 64 KB of dynamic LDS
-        const void *kernels[] = {
-            reinterpret_cast<const void *>(&tw_pipe_kernel<4, 16>), reinterpret_cast<const void *>(&tw_pipe_kernel<4, 8>),
-            reinterpret_cast<const void *>(&tw_pipe_kernel<4, 4>), reinterpret_cast<const void *>(&tw_pipe_kernel<4, 2>),
-            reinterpret_cast<const void *>(&tw_pipe_kernel<6, 16>), reinterpret_cast<const void *>(&tw_pipe_kernel<6, 8>),
-            reinterpret_cast<const void *>(&tw_pipe_kernel<6, 4>), reinterpret_cast<const void *>(&tw_pipe_kernel<6, 2>)};
+#define TW_PIPE_K(VAR, CD) reinterpret_cast<const void *>(&tw_pipe_kernel<VAR, 16, CD>), reinterpret_cast<const void *>(&tw_pipe_kernel<VAR, 8, CD>), \
+                           reinterpret_cast<const void *>(&tw_pipe_kernel<VAR, 4, CD>), reinterpret_cast<const void *>(&tw_pipe_kernel<VAR, 2, CD>)
+        const void *kernels[] = {TW_PIPE_K(4, false), TW_PIPE_K(4, true), TW_PIPE_K(6, false), TW_PIPE_K(6, true)};
+#undef TW_PIPE_K
         for (const void *k : kernels)
             if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PIPE_LDS_BYTES) != hipSuccess)
                 e->pipeline = 0;
