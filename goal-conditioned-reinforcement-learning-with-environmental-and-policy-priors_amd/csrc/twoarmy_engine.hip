@@ -1152,8 +1152,10 @@ __global__ __launch_bounds__(64) void tw_pipe_tables_kernel(uint32_t *tab, int V
     }
 }
 
-template <int VARIANT, int PG, bool CODE>
+// LAYOUT: 0 two float streams (obs rows, matrix rows), 1 one stream of float records (tw_alloc_outputs), 2 code frames
+template <int VARIANT, int PG, int LAYOUT>
 __global__ __launch_bounds__(64 * PWAVES, 16 / PWAVES) void tw_pipe_kernel(Params p) {
+    constexpr bool CODE = LAYOUT == 2;
     constexpr int PGRP = (CODE ? PGRP_CODE : PGRP_FLOAT) < PG ? (CODE ? PGRP_CODE : PGRP_FLOAT) : PG;
     extern __shared__ __attribute__((aligned(16))) uint32_t pipe_lds[];
     uint32_t *img = pipe_lds;                                   // [PWAVES][ENV_WORDS]
@@ -1180,7 +1182,7 @@ __global__ __launch_bounds__(64 * PWAVES, 16 / PWAVES) void tw_pipe_kernel(Param
     //   * the static image goes from the per-engine table straight into this wave's LDS copy (LDS-direct loads, no VGPRs;
     //     lane l of chunk k lands at my_img + 16 (64 k + l) bytes),
     //   * this lane's emission constants (same table), the block's records, the planes to verify, the first chunk's actions.
-    const bool record = p.record != 0;
+    constexpr bool record = LAYOUT == 1;                        // == (p.record != 0): the host picks the instantiation
     const uint4 *tab4 = reinterpret_cast<const uint4 *>(p.pipe_tab);
 #pragma unroll
     for (int k = 0; k < 6; ++k)
@@ -1898,14 +1900,17 @@ int launch_rollout(tw_engine *e, int T, const int32_t *actions, const uint32_t *
     // rounds, below ~2000 envs a second round would double the logic chain, which bounds the launch there).
     if (pg == 16 && (e->n_envs + 15) / 16 <= PIPE_WG_TARGET) pg = 8;
     const int grid = (e->n_envs + pg - 1) / pg;
-#define TW_PIPE_LAUNCH(VAR, PGV, CD) \
-    hipLaunchKernelGGL((tw_pipe_kernel<VAR, PGV, CD>), dim3(grid), dim3(64 * PWAVES), PIPE_LDS_BYTES, st, p)
-#define TW_PIPE_LAUNCH_PG(VAR, CD) do { \
-        if (pg == 16) TW_PIPE_LAUNCH(VAR, 16, CD); else if (pg == 8) TW_PIPE_LAUNCH(VAR, 8, CD); \
-        else if (pg == 4) TW_PIPE_LAUNCH(VAR, 4, CD); else TW_PIPE_LAUNCH(VAR, 2, CD); } while (0)
-    const bool codes = (flags & TW_F_MATRIX_CODE) != 0;
-    if (e->variant == 4) { if (codes) TW_PIPE_LAUNCH_PG(4, true); else TW_PIPE_LAUNCH_PG(4, false); }
-    else { if (codes) TW_PIPE_LAUNCH_PG(6, true); else TW_PIPE_LAUNCH_PG(6, false); }
+#define TW_PIPE_LAUNCH(VAR, PGV, LY) \
+    hipLaunchKernelGGL((tw_pipe_kernel<VAR, PGV, LY>), dim3(grid), dim3(64 * PWAVES), PIPE_LDS_BYTES, st, p)
+#define TW_PIPE_LAUNCH_PG(VAR, LY) do { \
+        if (pg == 16) TW_PIPE_LAUNCH(VAR, 16, LY); else if (pg == 8) TW_PIPE_LAUNCH(VAR, 8, LY); \
+        else if (pg == 4) TW_PIPE_LAUNCH(VAR, 4, LY); else TW_PIPE_LAUNCH(VAR, 2, LY); } while (0)
+    const int layout = (flags & TW_F_MATRIX_CODE) ? 2 : (p.record ? 1 : 0);
+    if (e->variant == 4) {
+        if (layout == 2) TW_PIPE_LAUNCH_PG(4, 2); else if (layout == 1) TW_PIPE_LAUNCH_PG(4, 1); else TW_PIPE_LAUNCH_PG(4, 0);
+    } else {
+        if (layout == 2) TW_PIPE_LAUNCH_PG(6, 2); else if (layout == 1) TW_PIPE_LAUNCH_PG(6, 1); else TW_PIPE_LAUNCH_PG(6, 0);
+    }
 #undef TW_PIPE_LAUNCH_PG
 #undef TW_PIPE_LAUNCH
     HIP_TRY(hipGetLastError());
@@ -1958,9 +1963,9 @@ int tw_create(tw_engine **out, int variant, int n_envs, int view_size, int devic
         if (me != hipSuccess) { tw_destroy(e); return hip_fail(me); }
     }
     {   // the pipelined kernel needs > 64 KB of dynamic LDS
-#define TW_PIPE_K(VAR, CD) reinterpret_cast<const void *>(&tw_pipe_kernel<VAR, 16, CD>), reinterpret_cast<const void *>(&tw_pipe_kernel<VAR, 8, CD>), \
-                           reinterpret_cast<const void *>(&tw_pipe_kernel<VAR, 4, CD>), reinterpret_cast<const void *>(&tw_pipe_kernel<VAR, 2, CD>)
-        const void *kernels[] = {TW_PIPE_K(4, false), TW_PIPE_K(4, true), TW_PIPE_K(6, false), TW_PIPE_K(6, true)};
+#define TW_PIPE_K(VAR, LY) reinterpret_cast<const void *>(&tw_pipe_kernel<VAR, 16, LY>), reinterpret_cast<const void *>(&tw_pipe_kernel<VAR, 8, LY>), \
+                           reinterpret_cast<const void *>(&tw_pipe_kernel<VAR, 4, LY>), reinterpret_cast<const void *>(&tw_pipe_kernel<VAR, 2, LY>)
+        const void *kernels[] = {TW_PIPE_K(4, 0), TW_PIPE_K(4, 1), TW_PIPE_K(4, 2), TW_PIPE_K(6, 0), TW_PIPE_K(6, 1), TW_PIPE_K(6, 2)};
 #undef TW_PIPE_K
         for (const void *k : kernels)
             if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PIPE_LDS_BYTES) != hipSuccess)

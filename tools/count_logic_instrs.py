@@ -16,7 +16,7 @@ def main():
     if "--no-build" not in sys.argv:
         subprocess.check_call(["make", "-s", "-C", CSRC, "asm"], stderr=subprocess.DEVNULL)
     s = open(os.path.join(CSRC, "twoarmy_engine.s")).read()
-    for m in re.finditer(r"^(_ZN\S*tw_pipe_kernelILi(\d)ELi(\d+)E\S*):", s, re.M):
+    for m in re.finditer(r"^(_ZN\S*tw_pipe_kernelILi(\d)ELi(\d+)ELi1E\S*):", s, re.M):
         a, b = m.end(), s.index(".Lfunc_end", m.end())
         body = s[a:b].split("\n")
         seg = [l for l in body if l.strip() and not l.strip().startswith((";", ".loc", ".cfi", ".p2align"))]
