@@ -11,7 +11,7 @@
         unsigned v0 = seed + threadIdx.x, v1 = seed * 3u, v2 = 5u, v3 = 7u, v4 = 11u;                             \
         unsigned long long t0, t1;                                                                                \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");                               \
-        asm volatile(".rept 512\n\t" body "\n\t.endr" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4) :: "vcc", "s20", "s21", "s22", "s23", "memory"); \
+        asm volatile(".rept 512\n\t" body "\n\t.endr\n9:" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4) :: "vcc", "s20", "s21", "s22", "s23", "memory"); \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");                               \
         if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = v0 + v1 + v2 + v3 + v4; }                               \
     }                                                                                                             \
@@ -29,6 +29,9 @@ TEST(bitop3, 1, "v_bitop3_b32 %0, %0, %1, %2 bitop3:0xc8")
 TEST(lshl_or, 1, "v_lshl_or_b32 %0, %1, 3, %0")
 TEST(saveexec, 3, "v_cmp_eq_u32 vcc, %0, %1\n\ts_and_saveexec_b64 s[22:23], vcc\n\ts_or_b64 exec, exec, s[22:23]")
 TEST(snop0, 1, "s_nop 0")
+TEST(cmp_vccnz, 2, "v_cmp_gt_u32 vcc, %0, %0\n\ts_cbranch_vccnz 9f")
+TEST(cmp_scc, 3, "v_cmp_gt_u32 vcc, %0, %0\n\ts_cmp_lg_u64 vcc, 0\n\ts_cbranch_scc1 9f")
+TEST(cmp_execnz, 4, "v_cmp_gt_u32 vcc, %0, %0\n\ts_and_saveexec_b64 s[22:23], vcc\n\ts_cbranch_execnz 9f\n\ts_or_b64 exec, exec, s[22:23]")
 TEST(dep_add_prio, 1, "v_add_u32 %0, %0, %1")
 __global__ void branch_taken(unsigned long long *out, unsigned seed) {
     unsigned long long t0, t1;
@@ -46,6 +49,6 @@ int main() {
     unsigned long long *d, h[2];
     CK(hipMalloc(&d, 16));
     RUN(dep_add); RUN(indep_add); RUN(cmp_cnd_vcc); RUN(cmp_nop_cnd); RUN(cmp_fill_cnd); RUN(cmp_sgpr_cnd); RUN(smov_vbfe);
-    RUN(salu_chain); RUN(salu_valu_mix); RUN(bitop3); RUN(lshl_or); RUN(saveexec); RUN(snop0); RUN(branch_taken);
+    RUN(salu_chain); RUN(salu_valu_mix); RUN(bitop3); RUN(lshl_or); RUN(saveexec); RUN(snop0); RUN(cmp_vccnz); RUN(cmp_scc); RUN(cmp_execnz); RUN(branch_taken);
     return 0;
 }

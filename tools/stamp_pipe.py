@@ -9,7 +9,7 @@ import numpy as np  # noqa
 import torch  # noqa
 import twoarmy_amd  # noqa
 from twoarmy_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libtwoarmy_hip_stamp.so")
+_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ.get("STAMP_LIB", "libtwoarmy_hip_stamp.so"))
 from twoarmy_amd.engine import TwoarmyEngine  # noqa
 variant = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
