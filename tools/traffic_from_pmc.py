@@ -21,7 +21,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-KERNEL = "tw_pipe_kernel<6, 16>"
+KERNEL = "tw_pipe_kernel<6, "        # <variant 6, envs per workgroup, layout>: the headline launches <6, 8, 1>
 ALGORITHMIC = (4 + 17 * 17 * 3 + 289 * 4 + 8 + 4 + 1 + 1 + 2 * (289 + 289 + 48 * 4) / 128.0) * 4096 * 128
 
 
