@@ -124,9 +124,6 @@ def build_parser():
                     help="rollout: 128 env-steps per launch (headline); step: one tw_step launch per env-step; "
                          "ppo: rollout with the actor in the loop + PPO update, gradient all-reduce per optimiser step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--placement-candidates", type=int, default=1,
-                    help="diagnostic: >1 probes that many torch-allocated output sets at set-up and keeps the fastest "
-                         "(the default output slab comes from the engine, tw_alloc_outputs)")
     ap.add_argument("--slab-check", type=int, default=3,
                     help="rollout mode: time the kernel into this many freshly allocated engine slabs at set-up and report "
                          "the values (evidence that placement no longer matters; nothing is selected); 1 = skip")
@@ -343,10 +340,8 @@ def run_engine_mode(args, rank, world, dev, coll):
     # the engine's own Philox stream, HBM-resident; launches cycle over a fixed window of it
     n_act = min(W + K, 64) if rollout else W + K
     actions = eng.fill_actions(n_act * T).view(n_act, T, N)
-    placement_ms, slab_check_ms, slabs = None, None, None
-    if rollout and args.placement_candidates > 1:
-        out, placement_ms = eng.alloc_outputs_tuned(T, candidates=args.placement_candidates, matrix_codes=args.matrix_codes)
-    elif args.torch_outputs or not rollout:
+    slab_check_ms, slabs = None, None
+    if args.torch_outputs or not rollout:
         out = eng.alloc_outputs(T if rollout else None, matrix_codes=args.matrix_codes, slab=False)
     else:
         out = eng.alloc_outputs(T, matrix_codes=args.matrix_codes)          # engine-owned slab (tw_alloc_outputs)
@@ -429,10 +424,9 @@ def run_engine_mode(args, rank, world, dev, coll):
                                       % ("u8-code" if args.matrix_codes else "f32"),
                    "parallelism": "env-sharded x%d, no data-path collective" % world,
                    "collective": coll,
-                   "output_buffers": "torch caching allocator, two streams" if (args.torch_outputs or placement_ms or not rollout)
+                   "output_buffers": "torch caching allocator, two streams" if (args.torch_outputs or not rollout)
                                      else "engine slab (tw_alloc_outputs): %s" % getattr(out["matrix"], "_tw_layout", "?"),
                    "slab_backing": backing,
-                   "output_placement_probe_ms": placement_ms,
                    "slab_check_ms": None if slab_check_ms is None else {
                        "what": "untimed set-up: kernel ms per launch into %d freshly allocated engine slabs; no selection, "
                                "the first one is used by the timed region" % len(slab_check_ms),

@@ -249,23 +249,6 @@ class TwoarmyEngine:
                     terminated=owner.tensor(o.terminated, TN, torch.uint8).view(lead),
                     truncated=owner.tensor(o.truncated, TN, torch.uint8).view(lead))
 
-    def alloc_outputs_tuned(self, T, candidates=6, iters=4, **kw):
-        """DIAGNOSTIC (round 1's placement probe, kept for tools/placement_probe*.py and `bench.py
-        --placement-candidates`): `candidates` two-stream output sets from torch's allocator are timed with real rollouts
-        and the fastest is kept; the env state is restored.  Not needed any more: alloc_outputs() hands out the engine's
-        record-layout slab, which is equally fast on every allocation.
-        Returns (outputs, probe_ms list)."""
-        state = self.get_state()
-        acts = self.fill_actions(T)
-        sets = [self.alloc_outputs(T, slab=False, **kw) for _ in range(int(candidates))]
-        ms = [self.time_rollout(T, o, actions=acts, iters=iters) for o in sets]
-        ms = [min(a, self.time_rollout(T, o, actions=acts, iters=iters)) for a, o in zip(ms, sets)]     # second pass: warm clocks
-        best = min(range(len(sets)), key=lambda k: ms[k])
-        out = sets[best]
-        del sets
-        self.set_state(*state)
-        return out, ms
-
     # ------------------------------------------------------------------ ops
     def reset(self, mask=None, obs=None):
         V = self.view_size

@@ -351,21 +351,6 @@ def test_full_size_properties():
     assert int(rec[:, _fields()["T"]].min()) == T
 
 
-def test_placement_tuned_outputs_leave_the_env_state_untouched():
-    """alloc_outputs_tuned probes candidate buffers with real rollouts; afterwards the envs are exactly where they
-    were, so the next rollout still equals the oracle from reset."""
-    N, T = 512, 64
-    eng = _engine(6, N, 17, seed=SEED)
-    out, ms = eng.alloc_outputs_tuned(T, candidates=3, iters=1)
-    assert len(ms) == 3 and all(m > 0 for m in ms)
-    ref = _oracle(6, N, T, 17, 0)
-    eng.rollout(T, out, actions=eng.fill_actions(T))
-    torch.cuda.synchronize()
-    for k in ("obs", "matrix", "pos", "reward", "terminated", "truncated"):
-        assert np.array_equal(out[k].cpu().numpy(), ref[k]), k
-    eng.close()
-
-
 def test_slab_free_then_realloc_writes_every_row():
     """Regression for the slab incident ("engine slab"): allocate a slab, roll out into it, drop it (so
     tw_free_outputs unmaps / releases its chunks), allocate again, prefill the new slab with 0x77 and run the pipelined

@@ -2,7 +2,7 @@
 set -o pipefail
 export PYTHONUNBUFFERED=1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-o=gpurun_out/r3f; mkdir -p $o
+o=gpurun_out/quick; mkdir -p $o
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 || exit 1
 timeout -k 10 900 python -m pytest tests/test_engine_gpu.py -x -q 2>&1 | tee $o/tests.log | tail -3
 [ ${PIPESTATUS[0]} -eq 0 ] || exit 1
@@ -13,7 +13,7 @@ for cfg in "v4 1024" "v6 1024" "v4 2048" "v6 4096" "v4 4096"; do
 done
 python - <<'PY'
 import json,glob,os
-for f in sorted(glob.glob('gpurun_out/r3f/bench_*.json')):
+for f in sorted(glob.glob('gpurun_out/quick/bench_*.json')):
     d=json.load(open(f)); r=d['roofline']
     print("%-24s %.3f G  kernel %.4f ms  frac %.3f" % (os.path.basename(f), d['value']/1e9, r['kernel_ms'], r['frac']))
 PY
