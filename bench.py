@@ -21,8 +21,9 @@ GPU), relays rank 0's JSON line and exits with the child's code.  Every rank ste
 "nccl" (= RCCL over xGMI) with one GPU per rank; one sanity all-reduce is recorded in the output.
 
 --mode ppo: BASELINE configs[2]/[3] loop (v4 by default): each step = one PPO iteration of the rank's envs
-(128-step rollout with the actor in the loop + K-epoch update); the gradient bucket all-reduce (dist.GradBucket,
-one flattened fp32 bucket per optimiser step) is timed with events and reported per optimiser step.
+(128-step rollout with the actor in the loop + K-epoch update, K = 10 and minibatch = buffer / 16 like the reference unless
+--k-epochs / --minibatch say otherwise); gradients go through dist.GradBucket (zero-copy views into one flat fp32 buffer, the
+actor's all-reduce overlaps the critic's backward); its exposed and stand-alone times are reported per optimiser step.
 """
 import argparse
 import json
@@ -135,8 +136,8 @@ def build_parser():
     ap.add_argument("--matrix-codes", action="store_true",
                     help="BASELINE configs[4] variant: state matrix as uint8 codes (TW_F_MATRIX_CODE), not the headline")
     # ppo mode
-    ap.add_argument("--minibatch", type=int, default=32768)
-    ap.add_argument("--k-epochs", type=int, default=1)
+    ap.add_argument("--minibatch", type=int, default=32768, help="ppo mode: samples per optimiser step (reference: buffer / 16, PPO.py:56,122: 32768 of 4096 x 128)")
+    ap.add_argument("--k-epochs", type=int, default=10, help="ppo mode: epochs per update (reference: K_epochs = 10, PPO.py:65)")
     ap.add_argument("--amp", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--her", action="store_true")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],

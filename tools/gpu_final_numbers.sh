@@ -18,8 +18,8 @@ for f in sorted(glob.glob('gpurun_out/final/bench_*.json')):
     except Exception as e:
         print(f, "ERR", e)
 PY
-timeout -k 10 600 python bench.py --mode ppo --steps 1 --warmup 1 > $o/bench_ppo_v4.json 2>> $o/err.log; python -c "
+timeout -k 10 600 python bench.py --mode ppo --k-epochs 1 --steps 1 --warmup 1 > $o/bench_ppo_v4.json 2>> $o/err.log; python -c "
 import json;d=json.load(open('$o/bench_ppo_v4.json'));c=d['config'];print('ppo v4', d['value'], c['rollout_s'], c['update_s'], c['update_targets_s'], c['update_epoch_s'], d['roofline']['achieved'])"
-timeout -k 10 600 python bench.py --mode ppo --steps 1 --warmup 1 --her > $o/bench_ppo_v4_her.json 2>> $o/err.log; python -c "
+timeout -k 10 600 python bench.py --mode ppo --k-epochs 1 --steps 1 --warmup 1 --her > $o/bench_ppo_v4_her.json 2>> $o/err.log; python -c "
 import json;d=json.load(open('$o/bench_ppo_v4_her.json'));c=d['config'];print('ppo v4 her', d['value'], c['rollout_s'], c['update_s'], c['her_records_per_iteration'])"
 python tools/ppo_kernels_bench.py > $o/ppo_kernels.json 2>> $o/err.log; tail -3 $o/ppo_kernels.json | cut -c1-300

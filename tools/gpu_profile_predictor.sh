@@ -2,8 +2,8 @@
 # MIOpen's find cache, then the same command under rocprofv3; top 40 kernels by total time -> gpurun_out/
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 300 python bench.py --mode ppo --predictor --matrix-codes --envs 2048 --steps 1 --warmup 1 > gpurun_out/r2_pred_warm.json 2> gpurun_out/r2_pred_warm.err || exit 1
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_pred -- python3 bench.py --mode ppo --predictor --matrix-codes --envs 2048 --steps 1 --warmup 1 > gpurun_out/r2_pred_under_rocprof.json 2> gpurun_out/r2_prof_pred.err || exit 1
+timeout -k 10 300 python bench.py --mode ppo --k-epochs 1 --predictor --matrix-codes --envs 2048 --steps 1 --warmup 1 > gpurun_out/r2_pred_warm.json 2> gpurun_out/r2_pred_warm.err || exit 1
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_pred -- python3 bench.py --mode ppo --k-epochs 1 --predictor --matrix-codes --envs 2048 --steps 1 --warmup 1 > gpurun_out/r2_pred_under_rocprof.json 2> gpurun_out/r2_prof_pred.err || exit 1
 f=$(find gpurun_out/prof_pred -name '*kernel_stats.csv' | head -1)
 python - "$f" <<'PY'
 import csv, sys

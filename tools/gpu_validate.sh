@@ -8,8 +8,8 @@ tail -12 gpurun_out/r2_suite_final.log
 [ $rc -eq 0 ] || exit $rc
 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r2_bench_final.json 2> gpurun_out/r2_bench_final.err || exit 1
 cut -c1-330 gpurun_out/r2_bench_final.json
-timeout -k 10 400 python bench.py --mode ppo --steps 2 --warmup 1 > gpurun_out/r2_bench_ppo_final.json 2> gpurun_out/r2_bench_ppo_final.err || exit 1
-timeout -k 10 400 python bench.py --gpus 2 --mode ppo --predictor --matrix-codes --envs 1024 --minibatch 8192 --steps 1 --warmup 1 > gpurun_out/r2_bench_ppo_predictor_n2_gloo.json 2> gpurun_out/r2_bench_ppo_predictor_n2_gloo.err || exit 1
+timeout -k 10 400 python bench.py --mode ppo --k-epochs 1 --steps 2 --warmup 1 > gpurun_out/r2_bench_ppo_final.json 2> gpurun_out/r2_bench_ppo_final.err || exit 1
+timeout -k 10 400 python bench.py --gpus 2 --mode ppo --k-epochs 1 --predictor --matrix-codes --envs 1024 --minibatch 8192 --steps 1 --warmup 1 > gpurun_out/r2_bench_ppo_predictor_n2_gloo.json 2> gpurun_out/r2_bench_ppo_predictor_n2_gloo.err || exit 1
 python - <<'PY'
 import json
 for f in ("r2_bench_ppo_final", "r2_bench_ppo_predictor_n2_gloo"):
