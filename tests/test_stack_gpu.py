@@ -209,6 +209,14 @@ def test_trainer_with_device_her_records():
         nv = agent.critic(agent.policy_input(s1), p1, h["goal"]).view(-1)
         want_t = h["reward"] + agent.gamma * nv
     assert torch.allclose(target[T * N:], want_t, atol=1e-5) and torch.allclose(adv[T * N:], want_t - v, atol=1e-5)
+    assert tr.her_out_of_pattern == 0              # the kernel emits runs of one episode under one goal: V(s') came from neighbours
+    # records in any other order (external `choices`, a changed kernel): the shortcut notices and evaluates their after-states
+    perm = torch.randperm(H, device=h["t"].device)
+    tr.her = {k: (val[perm].contiguous() if k != "counts" else val) for k, val in h.items()}
+    adv2, target2 = tr.compute_targets()
+    assert tr.her_out_of_pattern > 0
+    assert torch.allclose(target2[T * N:], want_t[perm], atol=1e-5) and torch.allclose(adv2[T * N:], (want_t - v)[perm], atol=1e-5)
+    tr.her = h
     total = T * N + H                           # whole minibatches only: every distinct batch size costs a MIOpen search
     la, lv = tr.update(permutations=[torch.randperm(total)[:total // 2048 * 2048]])
     assert np.isfinite(float(la)) and np.isfinite(float(lv)) and tr.her is None
