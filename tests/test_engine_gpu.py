@@ -212,6 +212,57 @@ def test_pipelined_equals_sequential_state(variant):
     assert a.fallback_count() == 0                 # normal play never leaves the pipelined path
 
 
+@pytest.mark.parametrize("variant", [6, 4])
+@pytest.mark.parametrize("T0", [37, 5])
+def test_pipelined_starts_from_a_sequential_kernel_state(variant, T0):
+    """Hand-over sequential -> pipelined: the logic wave derives its phases (step_move % 12, patrol bounce phases,
+    step_move - step_count, dropped wall blocks, episode coins) from records the SEQUENTIAL kernel wrote mid-episode.
+    A: T0 sequential steps, then 100 pipelined; B: everything sequential.  Same outputs, same final state, no fallback."""
+    N, T = 1000, 100
+    a, b = _engine(variant, N, 17, seed=SEED), _engine(variant, N, 17, seed=SEED)
+    b.set_pipeline(False)
+    acts = a.fill_actions(T0 + T)
+    for eng in (a, b):
+        eng.set_pipeline(False)
+        eng.rollout(T0, eng.alloc_outputs(T0), actions=acts[:T0].contiguous())
+    a.set_pipeline(True)
+    oa, ob = a.alloc_outputs(T), b.alloc_outputs(T)
+    a.rollout(T, oa, actions=acts[T0:].contiguous())
+    b.rollout(T, ob, actions=acts[T0:].contiguous())
+    torch.cuda.synchronize()
+    for k in oa:
+        assert torch.equal(oa[k], ob[k]), k
+    for x, y, name in zip(_canon(a.get_state()), _canon(b.get_state()), ("type", "colour", "records")):
+        assert np.array_equal(x, y), name
+    assert a.fallback_count() == 0
+
+
+def test_pipelined_after_a_mid_episode_reset_equals_sequential():
+    """MiniGridEnv.reset() in the middle of an episode leaves the Twoarmy flags armed (step_move, pone, ... SURVEY 3.1):
+    whatever the pipelined launch makes of such a state (closed form or fallback), it must equal the sequential kernel."""
+    N, T = 256, 64
+    a, b = _engine(4, N, 17, seed=SEED), _engine(4, N, 17, seed=SEED)
+    acts = a.fill_actions(20 + T)
+    for eng in (a, b):
+        eng.set_pipeline(False)
+        eng.rollout(20, eng.alloc_outputs(20), actions=acts[:20].contiguous())
+        eng.reset()
+    a.set_pipeline(True)
+    oa, ob = a.alloc_outputs(T), b.alloc_outputs(T)
+    a.rollout(T, oa, actions=acts[20:].contiguous())
+    b.rollout(T, ob, actions=acts[20:].contiguous())
+    torch.cuda.synchronize()
+    sa, sb = _canon(a.get_state()), _canon(b.get_state())
+    for x, y, name in zip(sa, sb, ("type", "colour", "records")):
+        assert np.array_equal(x, y), name
+    # v4 envs reset while their patrols existed hit `cur_pos is None` (TypeError, twoarmy_v4.py:122-124): raised steps
+    # leave their output rows unwritten, every other env's rows must agree
+    ok = torch.from_numpy(sa[2][:, _fields()["ERROR"]] == 0).cuda()
+    assert 0 < int(ok.sum()) < N
+    for k in oa:
+        assert torch.equal(oa[k][:, ok], ob[k][:, ok]), k
+
+
 def _canon(state):
     """Zero record fields that are meaningless in the current state (cur_pos of unspawned patrols, wall offsets
     before the drop): the reference objects simply do not exist then, the two kernels keep different leftovers."""
