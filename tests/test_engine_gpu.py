@@ -237,6 +237,28 @@ def test_pipelined_starts_from_a_sequential_kernel_state(variant, T0):
     assert a.fallback_count() == 0
 
 
+@pytest.mark.parametrize("variant,N,max_steps", [(6, 1, 50), (4, 3, 50), (4, 130, 23), (6, 700, 7)])
+def test_pipelined_tiny_batches_and_other_step_caps(variant, N, max_steps):
+    """Workgroups with a single real env (N = 1: one env, one padding lane) and MiniGridEnv(max_steps != 50): the
+    pipelined kernel against the sequential one, outputs and final state."""
+    T = 96
+    a = _engine(variant, N, 17, seed=SEED, env_id0=11, max_steps=max_steps)
+    b = _engine(variant, N, 17, seed=SEED, env_id0=11, max_steps=max_steps)
+    b.set_pipeline(False)
+    acts = a.fill_actions(T)
+    oa, ob = a.alloc_outputs(T), b.alloc_outputs(T)
+    a.rollout(T, oa, actions=acts)
+    b.rollout(T, ob, actions=acts)
+    torch.cuda.synchronize()
+    for k in oa:
+        assert torch.equal(oa[k], ob[k]), k
+    for x, y, name in zip(_canon(a.get_state()), _canon(b.get_state()), ("type", "colour", "records")):
+        assert np.array_equal(x, y), name
+    assert a.fallback_count() == 0
+    done = (ob["terminated"] | ob["truncated"]) != 0
+    assert int(done.sum()) >= (T // max_steps) * N                  # the cap really ends episodes
+
+
 def test_pipelined_after_a_mid_episode_reset_equals_sequential():
     """MiniGridEnv.reset() in the middle of an episode leaves the Twoarmy flags armed (step_move, pone, ... SURVEY 3.1):
     whatever the pipelined launch makes of such a state (closed form or fallback), it must equal the sequential kernel."""
