@@ -129,8 +129,8 @@ def build_parser():
                     help="rollout mode: time the kernel into this many freshly allocated engine slabs at set-up and report "
                          "the values (evidence that placement no longer matters; nothing is selected); 1 = skip")
     ap.add_argument("--regions", type=int, default=0,
-                    help="rollout/step mode: number of timed regions of --steps launches each (0 = auto: >= 25 and >= 100 ms "
-                         "of GPU time in total); the median region is reported")
+                    help="rollout/step mode: number of timed regions of --steps launches each (0 = auto: >= 25 regions and about "
+                         "1 s of GPU time in total, at most 400); the median region is reported")
     ap.add_argument("--torch-outputs", action="store_true",
                     help="diagnostic: outputs from torch's caching allocator instead of the engine's slab")
     ap.add_argument("--matrix-codes", action="store_true",
@@ -378,7 +378,8 @@ def run_engine_mode(args, rank, world, dev, coll):
     run(0, warm_launches - 8)
     # R timed regions of exactly K launches each, every one bracketed by barrier + synchronize on both sides; the line
     # reports the MEDIAN region (value, ms_per_step, roofline.kernel_ms) and the spread of all of them
-    R = args.regions if args.regions > 0 else min(400, max(25, int(110.0 / (K * est_ms)) + 1))
+    # auto: >= 25 regions and about one second of GPU time in total (a sampling monitor sees the kernel), at most 400 regions
+    R = args.regions if args.regions > 0 else min(400, max(25, int(1000.0 / (K * est_ms)) + 1))
     wall_s, ev_ms_all = [], []
     for r_ in range(R):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
