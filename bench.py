@@ -145,6 +145,9 @@ def build_parser():
     ap.add_argument("--nchw", action="store_true", help="ppo mode: literal NCHW nn.Sequential conv stacks (default: channels-last "
                     "+ fused epilogues)")
     ap.add_argument("--predictor", action="store_true", help="ppo mode: PPO + predictor head (configs[4])")
+    ap.add_argument("--miopen-benchmark", action="store_true",
+                    help="ppo mode: torch.backends.cudnn.benchmark = True (MIOpen benchmarks its solvers per conv shape once, "
+                         "minutes, instead of taking its heuristic pick)")
     ap.add_argument("--rehearse", action="store_true",
                     help="launcher / process-group plumbing only, no engine (for CPU-only hosts: gloo); the line "
                          "carries value 0 and \"data\": \"rehearsal\" and is not a measurement")
@@ -469,6 +472,8 @@ def run_ppo_mode(args, rank, world, dev, coll):
     K = args.steps if args.steps is not None else 2
     W = args.warmup if args.warmup is not None else 1
     torch.manual_seed(SEED)
+    if args.miopen_benchmark:
+        torch.backends.cudnn.benchmark = True
     if args.predictor:
         from twoarmy_amd.soa.agent.PPO_Predictor import ppo_predictor as Agent
     else:
@@ -547,7 +552,7 @@ def run_ppo_mode(args, rank, world, dev, coll):
                    "envs_per_gpu": N, "rollout_s": r, "update_s": u, "rollout_env_steps_per_s_per_gpu": S / r,
                    "update_targets_s": tr.last_update_timing["targets_s"], "update_epoch_s": tr.last_update_timing["epoch_s"],
                    "conv_layout": "nchw (literal nn.Sequential)" if args.nchw else "nhwc + fused upsample/conv1 and conv epilogues",
-                   "rollout_as_hip_graph": bool(tr.use_graph),
+                   "rollout_as_hip_graph": bool(tr.use_graph), "miopen_benchmark": bool(args.miopen_benchmark),
                    "her_records_per_iteration": sum(her_n) / max(1, len(her_n)),
                    "parallelism": "env-sharded x%d, one gradient-bucket all-reduce per optimiser step" % world,
                    "collective": coll,
