@@ -73,6 +73,12 @@ def traffic_from_profile(variant, n_envs, rollout_t, view, build_id=None, profil
     return None, "no counter profile of build %s (stale: %s); run tools/gpu_traffic.sh" % (build_id, "; ".join(stale))
 
 
+def auto_regions(K, est_ms):
+    """Number of timed regions of K launches each: at least 25, about one second of GPU time in total (a sampling
+    monitor then sees the kernel), at most 400.  Every rank calls this with the SAME est_ms (the slowest rank's)."""
+    return min(400, max(25, int(1000.0 / (K * est_ms)) + 1))
+
+
 def usable_cores():
     """Host cores this process may really use: the affinity mask, cut down by a cgroup CPU quota when there is one
     (the GPU boxes expose every core in the mask but schedule a share of them)."""
@@ -381,8 +387,7 @@ def run_engine_mode(args, rank, world, dev, coll):
     run(0, warm_launches - 8)
     # R timed regions of exactly K launches each, every one bracketed by barrier + synchronize on both sides; the line
     # reports the MEDIAN region (value, ms_per_step, roofline.kernel_ms) and the spread of all of them
-    # auto: >= 25 regions and about one second of GPU time in total (a sampling monitor sees the kernel), at most 400 regions
-    R = args.regions if args.regions > 0 else min(400, max(25, int(1000.0 / (K * est_ms)) + 1))
+    R = args.regions if args.regions > 0 else auto_regions(K, est_ms)
     wall_s, ev_ms_all = [], []
     for r_ in range(R):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -57,6 +57,13 @@ def test_library_reports_the_build_id_of_its_sources():
     assert twoarmy_amd._lib.lib().tw_build_id().decode() == h.hexdigest()[:16]
 
 
+def test_region_count_rule():
+    assert bench.auto_regions(20, 0.17) == 295                  # the driver's command at 4096 envs: ~1 s of GPU time
+    assert bench.auto_regions(20, 5.0) == 25                    # never fewer than 25 regions
+    assert bench.auto_regions(4, 0.05) == 400                   # ... nor more than 400
+    assert 0.9 < bench.auto_regions(40, 0.17) * 40 * 0.17 / 1000.0 < 1.1
+
+
 def test_cpu_baseline_leg_runs_the_oracle():
     assert 1 <= bench.usable_cores() <= 64
     r = bench.cpu_baseline(6, 256, 17, seconds=0.5)
